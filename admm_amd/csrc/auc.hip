@@ -1,0 +1,107 @@
+// Tie-aware rank-sum AUC on the device (Metrics::Sort + Metrics::Auc, src/metrics.cc:14-89):
+// radix sort of the scores, average 1-based rank per tie group, sum over positives in double.
+#include "internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+using namespace admm_impl;
+
+namespace admm_impl {
+
+// positives are rows whose label truncated to int equals 1 (src/metrics.cc:60,72)
+__global__ void __launch_bounds__(256) k_auc_flags(const float *__restrict__ label, uint32_t *__restrict__ flag,
+                                                   uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    flag[i] = ((int)label[i] == 1) ? 1u : 0u;
+}
+
+// start[i] = i where a tie group begins, else 0; an inclusive max-scan turns it into the group
+// start of every position
+__global__ void __launch_bounds__(256) k_auc_heads(const float *__restrict__ key, uint32_t *__restrict__ start,
+                                                   uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    start[i] = (i > 0 && key[i] != key[i - 1]) ? (uint32_t)i : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_auc_sum(const uint32_t *__restrict__ start,
+                                                 const uint32_t *__restrict__ flag, uint64_t n,
+                                                 double *__restrict__ partials) {
+  __shared__ double sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double rank_sum = 0, npos = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    if (!flag[i]) continue;
+    const uint32_t s = start[i];
+    // first position after i whose group start differs (start[] is non-decreasing)
+    uint64_t lo = i + 1, hi = n;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (start[mid] > s) hi = mid;
+      else lo = mid + 1;
+    }
+    rank_sum += ((double)s + (double)lo + 1.0) * 0.5;  // mean of ranks s+1 .. lo
+    npos += 1.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    rank_sum += __shfl_down(rank_sum, off, 64);
+    npos += __shfl_down(npos, off, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sh[wave] = rank_sum;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[0 * kMaxPartialBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  if (lane == 0) sh[wave] = npos;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[1 * kMaxPartialBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+int auc_device(admm_csr *csr, const float *scores, double *auc_out) {
+  admm_ctx *ctx = csr->ctx;
+  const uint64_t n = csr->nrows;
+  ADMM_REQUIRE(n < 0x7FFFFFFFull, "admm_metrics: AUC supports up to 2^31-1 rows");
+  float *keys = nullptr;
+  uint32_t *flag_in = nullptr, *flag_out = nullptr, *start = nullptr;
+  void *tmp = nullptr;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)keys, (void *)flag_in, (void *)flag_out, (void *)start, tmp})
+      if (p) hipFree(p);
+  };
+#define AUC_CHECK(expr)                                                        \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      set_error("admm_metrics(auc): %s: %s", #expr, hipGetErrorString(e_));    \
+      cleanup();                                                               \
+      return e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;        \
+    }                                                                          \
+  } while (0)
+  AUC_CHECK(hipMalloc(&keys, sizeof(float) * n));
+  AUC_CHECK(hipMalloc(&flag_in, sizeof(uint32_t) * n));
+  AUC_CHECK(hipMalloc(&flag_out, sizeof(uint32_t) * n));
+  AUC_CHECK(hipMalloc(&start, sizeof(uint32_t) * n));
+  const int grid = grid_for(n, 256, ctx->cu_count * 8);
+  hipLaunchKernelGGL(k_auc_flags, dim3(grid), dim3(256), 0, ctx->stream, csr->d_label, flag_in, n);
+  size_t bytes = 0, bytes2 = 0;
+  AUC_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, scores, keys, flag_in, flag_out, (size_t)n, 0, 32, ctx->stream));
+  AUC_CHECK(rocprim::inclusive_scan(nullptr, bytes2, start, start, (size_t)n, rocprim::maximum<uint32_t>(), ctx->stream));
+  if (bytes2 > bytes) bytes = bytes2;
+  AUC_CHECK(hipMalloc(&tmp, bytes ? bytes : 16));
+  AUC_CHECK(rocprim::radix_sort_pairs(tmp, bytes, scores, keys, flag_in, flag_out, (size_t)n, 0, 32, ctx->stream));
+  hipLaunchKernelGGL(k_auc_heads, dim3(grid), dim3(256), 0, ctx->stream, keys, start, n);
+  AUC_CHECK(rocprim::inclusive_scan(tmp, bytes, start, start, (size_t)n, rocprim::maximum<uint32_t>(), ctx->stream));
+  hipLaunchKernelGGL(k_auc_sum, dim3(grid), dim3(256), 0, ctx->stream, start, flag_out, n, ctx->d_partials);
+  AUC_CHECK(hipGetLastError());
+  int rc = finish_partials(ctx, 2, grid);
+  cleanup();
+#undef AUC_CHECK
+  if (rc != ADMM_OK) return rc;
+  const double rank_sum = ctx->h_scalars[0], P = ctx->h_scalars[1], N = (double)n - P;
+  // src/metrics.cc:80; with one class missing this divides by zero exactly as the reference does
+  *auc_out = rank_sum / (P * N) - (P + 1.0) / (2.0 * N);
+  return ADMM_OK;
+}
+
+}  // namespace admm_impl

@@ -1,0 +1,581 @@
+// Sample sets in HBM: CSR upload with the bias shift, the column-block ("transposed") copy, and
+// the on-device synthetic generator.
+#include "internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+using namespace admm_impl;
+
+namespace admm_impl {
+
+// ---- bias shift on the device (src/sample_set.cc:70-88) --------------------------------------
+
+// rowptr'[r] = rowptr[r] + r ; entry 0 of every row is (col 0, val 1); the rest is col+1.
+__global__ void __launch_bounds__(256) k_translate(const uint64_t *__restrict__ rowptr_in,
+                                                   const uint32_t *__restrict__ col_in,
+                                                   const float *__restrict__ val_in,
+                                                   uint64_t nrows, uint64_t *__restrict__ rowptr_out,
+                                                   uint32_t *__restrict__ col_out,
+                                                   float *__restrict__ val_out) {
+  // one 16-lane group per row
+  const int sub = threadIdx.x & 15;
+  const uint64_t grp = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const uint64_t ngrp = ((uint64_t)gridDim.x * 256) >> 4;
+  for (uint64_t r = grp; r < nrows; r += ngrp) {
+    const uint64_t b = rowptr_in[r], e = rowptr_in[r + 1];
+    const uint64_t ob = b + r;
+    if (sub == 0) {
+      rowptr_out[r] = ob;
+      col_out[ob] = 0u;
+      if (val_out) val_out[ob] = 1.0f;
+      if (r == nrows - 1) rowptr_out[nrows] = e + nrows;
+    }
+    for (uint64_t k = b + sub; k < e; k += 16) {
+      col_out[ob + 1 + (k - b)] = col_in[k] + 1u;
+      if (val_out) val_out[ob + 1 + (k - b)] = val_in ? val_in[k] : 1.0f;
+    }
+  }
+}
+
+// ---- column-block copy ------------------------------------------------------------------------
+//
+// Rows are cut into panels of P rows, columns into blocks of CB columns.  Cell (p, b) holds the
+// entries of panel p whose column lies in block b, as three parallel arrays (row u32, local
+// column u16, value f32).  Inside a cell the entries of one build chunk (kChunkRows consecutive
+// rows) are contiguous, so a sweep over a cell reads the per-row vector almost sequentially while
+// its per-column accumulators live in LDS.  The bias column (col 0 of a bias-shifted set) is left
+// out: it is present in every row and is reduced by the forward sweep instead.
+
+constexpr int kChunkRows = 512;
+
+struct TBuildArgs {
+  const uint64_t *rowptr;
+  const uint32_t *col;
+  const float *val;
+  uint64_t nrows, panel_rows;
+  uint32_t col_block, nblocks;
+  int skip_bias;
+  unsigned long long *cell_count;   // pass 1: entries per cell
+  unsigned long long *cell_cursor;  // pass 2: next free slot per cell (starts at tptr[cell])
+  uint32_t *trow;
+  uint16_t *tcol;
+  float *tval;
+};
+
+// LDS histogram over the column blocks of one chunk of rows; pass 1 adds it to the global cell
+// counts, pass 2 reserves a contiguous range per (chunk, block) and scatters the entries.
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
+  extern __shared__ uint32_t sh[];  // [nblocks] counts, then (SCATTER) [nblocks*2] bases lo/hi
+  uint32_t *cnt = sh;
+  const uint64_t chunks_per_panel = (a.panel_rows + kChunkRows - 1) / kChunkRows;
+  const uint64_t nchunks_total = ((a.nrows + a.panel_rows - 1) / a.panel_rows) * chunks_per_panel;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks_total; chunk += gridDim.x) {
+    const uint64_t panel = chunk / chunks_per_panel;
+    const uint64_t r0 = panel * a.panel_rows + (chunk % chunks_per_panel) * kChunkRows;
+    uint64_t r1 = r0 + kChunkRows;
+    const uint64_t pend = (panel + 1) * a.panel_rows;
+    if (r1 > pend) r1 = pend;
+    if (r1 > a.nrows) r1 = a.nrows;
+    if (r0 >= r1) continue;  // uniform per block
+    for (uint32_t i = threadIdx.x; i < a.nblocks; i += 256) cnt[i] = 0;
+    __syncthreads();
+    const uint64_t kb = a.rowptr[r0], ke = a.rowptr[r1];
+    for (uint64_t k = kb + threadIdx.x; k < ke; k += 256) {
+      const uint32_t c = a.col[k];
+      if (a.skip_bias && c == 0) continue;
+      atomicAdd(&cnt[c / a.col_block], 1u);
+    }
+    __syncthreads();
+    if (!SCATTER) {
+      for (uint32_t i = threadIdx.x; i < a.nblocks; i += 256)
+        if (cnt[i]) atomicAdd(&a.cell_count[panel * a.nblocks + i], (unsigned long long)cnt[i]);
+      __syncthreads();
+    } else {
+      unsigned long long *base = reinterpret_cast<unsigned long long *>(sh + ((a.nblocks + 1) & ~1u));
+      for (uint32_t i = threadIdx.x; i < a.nblocks; i += 256) {
+        base[i] = cnt[i] ? atomicAdd(&a.cell_cursor[panel * a.nblocks + i], (unsigned long long)cnt[i]) : 0ull;
+        cnt[i] = 0;
+      }
+      __syncthreads();
+      // entries of one row keep their row id; find it by walking rows per thread group:
+      // each 16-lane group takes rows r0+g, r0+g+16, ...
+      const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+      for (uint64_t r = r0 + grp; r < r1; r += 16) {
+        const uint64_t b = a.rowptr[r], e = a.rowptr[r + 1];
+        for (uint64_t k = b + sub; k < e; k += 16) {
+          const uint32_t c = a.col[k];
+          if (a.skip_bias && c == 0) continue;
+          const uint32_t blk = c / a.col_block;
+          const uint32_t slot = atomicAdd(&cnt[blk], 1u);
+          const uint64_t pos = base[blk] + slot;
+          a.trow[pos] = (uint32_t)r;
+          a.tcol[pos] = (uint16_t)(c - blk * a.col_block);
+          if (a.tval) a.tval[pos] = a.val[k];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- synthetic generator ------------------------------------------------------------------------
+
+__device__ __host__ inline uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ inline float u01(uint64_t h) { return (float)((h >> 40) + 1) * (1.0f / 16777217.0f); }  // (0,1)
+__device__ inline float normal01(uint64_t h) {
+  const float u1 = u01(h), u2 = u01(mix64(h ^ 0xA5A5A5A5A5A5A5A5ull));
+  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+// bijection on [0, nfeat): multiply-xorshift on kbits bits with cycle walking
+__device__ inline uint32_t scatter_id(uint32_t x, uint32_t nfeat, int kbits) {
+  const uint32_t mask = kbits >= 32 ? 0xFFFFFFFFu : ((1u << kbits) - 1u);
+  do {
+    x = (x * 0x9E3779B1u + 0x7F4A7C15u) & mask;
+    x ^= x >> ((kbits + 1) / 2);
+    x = (x * 0x85EBCA6Bu) & mask;
+    x ^= x >> ((kbits + 1) / 2);
+  } while (x >= nfeat);
+  return x;
+}
+
+__device__ inline float wstar_of(uint64_t seed, uint32_t id) {
+  const uint64_t h = mix64(seed ^ (0xC0FFEEull << 20) ^ id);
+  if ((h & 0xFF) >= 77) return 0.0f;  // ~30 % of the features carry signal
+  return 0.7f * normal01(mix64(h));
+}
+
+struct SynthArgs {
+  admm_synth_spec s;
+  uint32_t nfeat;
+  int kbits;
+  float zipf_a, zipf_top;  // a = 1 - s ; top = (nfeat+1)^a - 1
+  float ln_mu;
+  uint64_t *rowlen;        // pass 1 output (entries per row incl. bias)
+  const uint64_t *rowptr;  // pass 2 input
+  uint32_t *col;
+  float *val;
+  float *label;
+};
+
+// One 64-lane workgroup per row (grid-stride): draw ids into LDS, bitonic sort, drop duplicates.
+template <bool WRITE>
+__global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
+  __shared__ uint32_t ids[1024];
+  __shared__ uint32_t outn;
+  const int lane = threadIdx.x;
+  for (uint64_t r = blockIdx.x; r < a.s.nrows; r += gridDim.x) {
+    const uint64_t grow = a.s.row_offset + r;
+    const uint64_t hrow = mix64(a.s.seed * 0x100000001B3ull + grow);
+    // row length
+    float lf;
+    if (a.s.len_dist == 1) {
+      lf = expf(a.ln_mu + a.s.tail_sigma * normal01(hrow));
+    } else {
+      lf = a.s.mean_nnz + sqrtf(a.s.mean_nnz) * normal01(hrow);
+    }
+    int len = (int)floorf(lf + 0.5f);
+    if (len < 0) len = 0;
+    if (len > (int)a.s.max_len) len = (int)a.s.max_len;
+    int n2 = 64;
+    while (n2 < len) n2 <<= 1;
+    for (int k = lane; k < n2; k += 64) {
+      uint32_t id = 0xFFFFFFFFu;
+      if (k < len) {
+        const float u = u01(mix64(hrow + 0x632BE59BD9B4E019ull * (uint64_t)(k + 1)));
+        float x = powf(u * a.zipf_top + 1.0f, 1.0f / a.zipf_a);  // in [1, nfeat+1)
+        uint32_t rank = (uint32_t)x;
+        rank = rank < 1 ? 0 : rank - 1;
+        if (rank >= a.nfeat) rank = a.nfeat - 1;
+        id = scatter_id(rank, a.nfeat, a.kbits);
+      }
+      ids[k] = id;
+    }
+    __syncthreads();
+    // bitonic sort of n2 keys by one wave
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = lane; t < (n2 >> 1); t += 64) {
+          const int i = 2 * t - (t & (stride - 1));
+          const int j = i + stride;
+          const bool up = ((i & size) == 0);
+          const uint32_t x = ids[i], y = ids[j];
+          if ((x > y) == up) {
+            ids[i] = y;
+            ids[j] = x;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // unique + compaction (+ hidden-model margin for the label)
+    if (lane == 0) outn = 0;
+    __syncthreads();
+    const uint64_t ob = WRITE ? a.rowptr[r] : 0;
+    float margin = 0.0f;
+    for (int base = 0; base < n2; base += 64) {
+      const int k = base + lane;
+      const uint32_t id = ids[k];
+      const bool keep = id != 0xFFFFFFFFu && (k == 0 || ids[k - 1] != id);
+      const unsigned long long m = __ballot(keep);
+      const uint32_t before = outn + __popcll(m & ((1ull << lane) - 1ull));
+      if (WRITE && keep) {
+        a.col[ob + 1 + before] = id + 1u;
+        a.val[ob + 1 + before] = 1.0f;
+        margin += wstar_of(a.s.seed, id);
+      }
+      __syncthreads();
+      if (lane == 0) outn += (uint32_t)__popcll(m);
+      __syncthreads();
+    }
+    if (WRITE) {
+      for (int off = 32; off > 0; off >>= 1) margin += __shfl_down(margin, off, 64);
+      if (lane == 0) {
+        a.col[ob] = 0u;
+        a.val[ob] = 1.0f;
+        const float p = 1.0f / (1.0f + expf(-(margin - 0.5f)));
+        a.label[r] = u01(mix64(hrow ^ 0x1234567ull)) < p ? 1.0f : 0.0f;
+      }
+    } else if (lane == 0) {
+      a.rowlen[r] = (uint64_t)outn + 1u;
+    }
+    __syncthreads();
+  }
+}
+
+int ensure_rowbuf(admm_csr *csr) {
+  if (csr->d_rowbuf || csr->nrows == 0) return ADMM_OK;
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_rowbuf, sizeof(float) * csr->nrows));
+  return ADMM_OK;
+}
+
+int ensure_taccum(admm_csr *csr) {
+  if (csr->d_g1) return ADMM_OK;
+  const uint64_t padded = (uint64_t)csr->nblocks * csr->col_block;
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_g1, sizeof(float) * padded));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_g2, sizeof(float) * padded));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_mask, sizeof(uint32_t) * (padded / 32 + 1)));
+  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g1, 0, sizeof(float) * padded, csr->ctx->stream));
+  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g2, 0, sizeof(float) * padded, csr->ctx->stream));
+  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_mask, 0, sizeof(uint32_t) * (padded / 32 + 1), csr->ctx->stream));
+  return ADMM_OK;
+}
+
+static void pick_lpr(admm_csr *csr) {
+  const double mean = csr->nrows ? (double)csr->nnz / (double)csr->nrows : 1.0;
+  uint32_t lpr = 4;
+  while (lpr < 64 && mean > 4.0 * lpr) lpr <<= 1;
+  csr->fwd_lpr = lpr;
+}
+
+static void free_csr(admm_csr *c) {
+  if (!c) return;
+  if (c->ctx) {
+    hipSetDevice(c->ctx->device);
+    hipStreamSynchronize(c->ctx->stream);
+  }
+  void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_tptr,
+                  c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  delete c;
+}
+
+}  // namespace admm_impl
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint32_t *col,
+                               const float *val, const float *label, uint64_t nrows, uint64_t nnz,
+                               uint64_t dim, int add_bias, admm_csr **out) {
+  ADMM_REQUIRE(ctx && rowptr && label && out, "admm_csr_upload: NULL argument");
+  ADMM_REQUIRE(nnz == 0 || col, "admm_csr_upload: col is NULL");
+  ADMM_REQUIRE(dim > 0 && dim <= 0xFFFFFFFFull, "admm_csr_upload: dim %llu out of range",
+               (unsigned long long)dim);
+  ADMM_REQUIRE(nrows < 0xFFFFFFFFull, "admm_csr_upload: at most 2^32-1 rows per sample set");
+  ADMM_REQUIRE(rowptr[0] == 0 && rowptr[nrows] == nnz, "admm_csr_upload: rowptr does not span nnz");
+  // host-side validation: monotone rowptr, index range (dmlc's SDot CHECKs index < size),
+  // duplicate columns inside a row
+  bool dup = false;
+  const uint64_t limit = add_bias ? dim - 1 : dim;
+  for (uint64_t r = 0; r < nrows; ++r) {
+    ADMM_REQUIRE(rowptr[r] <= rowptr[r + 1], "admm_csr_upload: rowptr decreases at row %llu",
+                 (unsigned long long)r);
+    for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      ADMM_REQUIRE(col[k] < limit, "admm_csr_upload: feature index %u of row %llu needs dim > %llu",
+                   col[k], (unsigned long long)r, (unsigned long long)(add_bias ? col[k] + 1 : col[k]));
+      if (!dup)
+        for (uint64_t q = rowptr[r]; q < k; ++q)
+          if (col[q] == col[k]) {
+            dup = true;
+            break;
+          }
+    }
+  }
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  admm_csr *c = new admm_csr();
+  c->ctx = ctx;
+  c->nrows = nrows;
+  c->dim = dim;
+  c->has_bias = add_bias != 0;
+  c->has_dup_cols = dup;
+  c->nnz = add_bias ? nnz + nrows : nnz;
+  const bool keep_val = val != nullptr || add_bias;  // the bias entry carries an explicit 1
+  int rc = ADMM_OK;
+  auto fail = [&](int code) {
+    free_csr(c);
+    return code;
+  };
+#define UP_CHECK(expr)                                                                     \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      set_error("%s failed: %s", #expr, hipGetErrorString(e_));                            \
+      return fail(e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP);              \
+    }                                                                                      \
+  } while (0)
+  UP_CHECK(hipMalloc(&c->d_rowptr, sizeof(uint64_t) * (nrows + 1)));
+  UP_CHECK(hipMalloc(&c->d_col, sizeof(uint32_t) * std::max<uint64_t>(c->nnz, 1)));
+  if (keep_val) UP_CHECK(hipMalloc(&c->d_val, sizeof(float) * std::max<uint64_t>(c->nnz, 1)));
+  UP_CHECK(hipMalloc(&c->d_label, sizeof(float) * std::max<uint64_t>(nrows, 1)));
+  if (nrows) UP_CHECK(hipMemcpyAsync(c->d_label, label, sizeof(float) * nrows, hipMemcpyHostToDevice, ctx->stream));
+  if (!add_bias) {
+    UP_CHECK(hipMemcpyAsync(c->d_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) UP_CHECK(hipMemcpyAsync(c->d_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    if (val && nnz) UP_CHECK(hipMemcpyAsync(c->d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    UP_CHECK(hipStreamSynchronize(ctx->stream));
+  } else {
+    uint64_t *t_rowptr = nullptr;
+    uint32_t *t_col = nullptr;
+    float *t_val = nullptr;
+    UP_CHECK(hipMalloc(&t_rowptr, sizeof(uint64_t) * (nrows + 1)));
+    UP_CHECK(hipMalloc(&t_col, sizeof(uint32_t) * std::max<uint64_t>(nnz, 1)));
+    if (val) UP_CHECK(hipMalloc(&t_val, sizeof(float) * std::max<uint64_t>(nnz, 1)));
+    UP_CHECK(hipMemcpyAsync(t_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) UP_CHECK(hipMemcpyAsync(t_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    if (val && nnz) UP_CHECK(hipMemcpyAsync(t_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    if (nrows) {
+      const int grid = grid_for(nrows * 16, 256, ctx->cu_count * 8);
+      hipLaunchKernelGGL(k_translate, dim3(grid), dim3(256), 0, ctx->stream, t_rowptr, t_col, t_val,
+                         nrows, c->d_rowptr, c->d_col, c->d_val);
+    } else {
+      UP_CHECK(hipMemsetAsync(c->d_rowptr, 0, sizeof(uint64_t), ctx->stream));
+    }
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(t_rowptr);
+    hipFree(t_col);
+    if (t_val) hipFree(t_val);
+    UP_CHECK(e1);
+    UP_CHECK(e2);
+  }
+#undef UP_CHECK
+  pick_lpr(c);
+  (void)rc;
+  *out = c;
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_shape(const admm_csr *csr, uint64_t *nrows, uint64_t *nnz, uint64_t *dim) {
+  ADMM_REQUIRE(csr, "admm_csr_shape: csr is NULL");
+  if (nrows) *nrows = csr->nrows;
+  if (nnz) *nnz = csr->nnz;
+  if (dim) *dim = csr->dim;
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t *transposed_bytes) {
+  ADMM_REQUIRE(csr, "admm_csr_bytes: csr is NULL");
+  if (csr_bytes)
+    *csr_bytes = 8 * (csr->nrows + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * csr->nrows;
+  if (transposed_bytes)
+    *transposed_bytes = csr->has_t ? 8 * (csr->npanels * csr->nblocks + 1) + 6 * csr->tnnz +
+                                         (csr->d_tval ? 4 * csr->tnnz : 0)
+                                   : 0;
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, float *val,
+                                 float *label) {
+  ADMM_REQUIRE(csr, "admm_csr_download: csr is NULL");
+  admm_ctx *ctx = csr->ctx;
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (rowptr) ADMM_HIP_CHECK(hipMemcpy(rowptr, csr->d_rowptr, sizeof(uint64_t) * (csr->nrows + 1), hipMemcpyDeviceToHost));
+  if (col && csr->nnz) ADMM_HIP_CHECK(hipMemcpy(col, csr->d_col, sizeof(uint32_t) * csr->nnz, hipMemcpyDeviceToHost));
+  if (val && csr->nnz) {
+    if (csr->d_val) {
+      ADMM_HIP_CHECK(hipMemcpy(val, csr->d_val, sizeof(float) * csr->nnz, hipMemcpyDeviceToHost));
+    } else {
+      for (uint64_t i = 0; i < csr->nnz; ++i) val[i] = 1.0f;
+    }
+  }
+  if (label && csr->nrows) ADMM_HIP_CHECK(hipMemcpy(label, csr->d_label, sizeof(float) * csr->nrows, hipMemcpyDeviceToHost));
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_destroy(admm_csr *csr) {
+  free_csr(csr);
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block) {
+  ADMM_REQUIRE(csr, "admm_csr_build_transposed: csr is NULL");
+  admm_ctx *ctx = csr->ctx;
+  if (col_block == 0) col_block = 16384;
+  ADMM_REQUIRE(col_block <= 16384 && col_block >= 64 && (col_block % 64) == 0,
+               "admm_csr_build_transposed: col_block must be a multiple of 64 in [64, 16384]");
+  if (panel_rows == 0) panel_rows = 1u << 20;
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  // drop a previous copy
+  for (void **p : {(void **)&csr->d_tptr, (void **)&csr->d_trow, (void **)&csr->d_tcol, (void **)&csr->d_tval,
+                   (void **)&csr->d_g1, (void **)&csr->d_g2, (void **)&csr->d_mask}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  csr->has_t = false;
+  csr->panel_rows = panel_rows;
+  csr->col_block = col_block;
+  csr->nblocks = (uint32_t)((csr->dim + col_block - 1) / col_block);
+  csr->npanels = csr->nrows ? (csr->nrows + panel_rows - 1) / panel_rows : 0;
+  const uint64_t ncells = csr->npanels * csr->nblocks;
+  ADMM_REQUIRE(csr->nblocks <= 8192, "admm_csr_build_transposed: too many column blocks (%u)", csr->nblocks);
+  csr->h_tptr.assign(ncells + 1, 0);
+  unsigned long long *d_cnt = nullptr;
+  ADMM_HIP_CHECK(hipMalloc(&d_cnt, sizeof(unsigned long long) * (ncells + 1)));
+  ADMM_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * (ncells + 1), ctx->stream));
+  TBuildArgs a{};
+  a.rowptr = csr->d_rowptr;
+  a.col = csr->d_col;
+  a.val = csr->d_val;
+  a.nrows = csr->nrows;
+  a.panel_rows = panel_rows;
+  a.col_block = col_block;
+  a.nblocks = csr->nblocks;
+  a.skip_bias = csr->has_bias ? 1 : 0;
+  a.cell_count = d_cnt;
+  const uint64_t chunks = csr->npanels * ((panel_rows + kChunkRows - 1) / kChunkRows);
+  const int grid = grid_for(chunks * 256, 256, ctx->cu_count * 8);
+  const size_t lds1 = sizeof(uint32_t) * csr->nblocks;
+  const size_t lds2 = sizeof(uint32_t) * ((csr->nblocks + 1) & ~1u) + sizeof(unsigned long long) * csr->nblocks;
+  if (csr->nrows) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tbuild<false>), dim3(grid), dim3(256), lds1, ctx->stream, a);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  std::vector<unsigned long long> h_cnt(ncells + 1, 0);
+  ADMM_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), d_cnt, sizeof(unsigned long long) * ncells, hipMemcpyDeviceToHost, ctx->stream));
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  uint64_t run = 0;
+  for (uint64_t i = 0; i < ncells; ++i) {
+    csr->h_tptr[i] = run;
+    run += h_cnt[i];
+  }
+  csr->h_tptr[ncells] = run;
+  csr->tnnz = run;
+  const uint64_t expect = csr->has_bias ? csr->nnz - csr->nrows : csr->nnz;
+  if (run != expect) {
+    hipFree(d_cnt);
+    set_error("admm_csr_build_transposed: counted %llu entries, expected %llu",
+              (unsigned long long)run, (unsigned long long)expect);
+    return ADMM_ERR_STATE;
+  }
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_tptr, sizeof(uint64_t) * (ncells + 1)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_trow, sizeof(uint32_t) * std::max<uint64_t>(run, 1)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_tcol, sizeof(uint16_t) * std::max<uint64_t>(run, 1)));
+  if (csr->d_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_tval, sizeof(float) * std::max<uint64_t>(run, 1)));
+  ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_tptr, csr->h_tptr.data(), sizeof(uint64_t) * (ncells + 1), hipMemcpyHostToDevice, ctx->stream));
+  // cursors start at the cell bases
+  ADMM_HIP_CHECK(hipMemcpyAsync(d_cnt, csr->h_tptr.data(), sizeof(uint64_t) * (ncells + 1), hipMemcpyHostToDevice, ctx->stream));
+  a.cell_cursor = d_cnt;
+  a.trow = csr->d_trow;
+  a.tcol = csr->d_tcol;
+  a.tval = csr->d_tval;
+  if (csr->nrows) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tbuild<true>), dim3(grid), dim3(256), lds2, ctx->stream, a);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  hipFree(d_cnt);
+  csr->has_t = true;
+  ADMM_TRY(ensure_taccum(csr));
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_csr **out) {
+  ADMM_REQUIRE(ctx && spec && out, "admm_csr_synth: NULL argument");
+  ADMM_REQUIRE(spec->dim >= 3 && spec->dim <= 0xFFFFFFFFull, "admm_csr_synth: dim out of range");
+  ADMM_REQUIRE(spec->max_len >= 1 && spec->max_len <= 1024, "admm_csr_synth: max_len must be in [1, 1024]");
+  ADMM_REQUIRE(spec->zipf_s > 1.0f, "admm_csr_synth: zipf_s must be > 1");
+  ADMM_REQUIRE(spec->nrows < 0xFFFFFFFFull, "admm_csr_synth: at most 2^32-1 rows per sample set");
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  admm_csr *c = new admm_csr();
+  c->ctx = ctx;
+  c->nrows = spec->nrows;
+  c->dim = spec->dim;
+  c->has_bias = true;
+  SynthArgs a{};
+  a.s = *spec;
+  a.nfeat = (uint32_t)(spec->dim - 1);
+  a.kbits = 1;
+  while ((1ull << a.kbits) < a.nfeat) ++a.kbits;
+  a.zipf_a = 1.0f - spec->zipf_s;
+  a.zipf_top = powf((float)a.nfeat + 1.0f, a.zipf_a) - 1.0f;
+  a.ln_mu = logf(spec->mean_nnz) - 0.5f * spec->tail_sigma * spec->tail_sigma;
+  auto fail = [&](const char *what, hipError_t e) {
+    set_error("admm_csr_synth: %s: %s", what, hipGetErrorString(e));
+    free_csr(c);
+    return e == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;
+  };
+  hipError_t e;
+  uint64_t *d_len = nullptr;
+  const uint64_t n = spec->nrows;
+  if ((e = hipMalloc(&c->d_rowptr, sizeof(uint64_t) * (n + 1))) != hipSuccess) return fail("rowptr", e);
+  if ((e = hipMalloc(&d_len, sizeof(uint64_t) * (n + 1))) != hipSuccess) return fail("rowlen", e);
+  if ((e = hipMalloc(&c->d_label, sizeof(float) * std::max<uint64_t>(n, 1))) != hipSuccess) {
+    hipFree(d_len);
+    return fail("label", e);
+  }
+  hipMemsetAsync(d_len, 0, sizeof(uint64_t) * (n + 1), ctx->stream);
+  const int grid = grid_for(n * 64, 64, ctx->cu_count * 32);
+  a.rowlen = d_len;
+  if (n) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_synth<false>), dim3(grid), dim3(64), 0, ctx->stream, a);
+  // exclusive scan of n+1 lengths (last is 0) -> rowptr[0..n]
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_len, c->d_rowptr, (int64_t)(n + 1), ctx->stream);
+  if ((e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16))) != hipSuccess) {
+    hipFree(d_len);
+    return fail("scan scratch", e);
+  }
+  hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_len, c->d_rowptr, (int64_t)(n + 1), ctx->stream);
+  uint64_t total = 0;
+  hipMemcpyAsync(&total, c->d_rowptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+  e = hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  hipFree(d_len);
+  if (e != hipSuccess) return fail("length pass", e);
+  c->nnz = total;
+  if ((e = hipMalloc(&c->d_col, sizeof(uint32_t) * std::max<uint64_t>(total, 1))) != hipSuccess) return fail("col", e);
+  if ((e = hipMalloc(&c->d_val, sizeof(float) * std::max<uint64_t>(total, 1))) != hipSuccess) return fail("val", e);
+  a.rowptr = c->d_rowptr;
+  a.col = c->d_col;
+  a.val = c->d_val;
+  a.label = c->d_label;
+  if (n) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_synth<true>), dim3(grid), dim3(64), 0, ctx->stream, a);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("fill pass launch", e);
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("fill pass", e);
+  pick_lpr(c);
+  *out = c;
+  return ADMM_OK;
+}

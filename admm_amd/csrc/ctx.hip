@@ -1,0 +1,428 @@
+// Context, device vectors, timing and the dim-sized elementwise kernels of the consensus step.
+#include "internal.h"
+
+#include <cstring>
+
+namespace admm_impl {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+// ---- timing -------------------------------------------------------------------------------
+
+int timing_begin(admm_ctx *ctx, int kernel) {
+  TimingSlot s;
+  if (!ctx->free_slots.empty()) {
+    s = ctx->free_slots.back();
+    ctx->free_slots.pop_back();
+  } else {
+    if (ctx->pending.size() >= 8192) timing_flush(ctx);
+    if (!ctx->free_slots.empty()) {
+      s = ctx->free_slots.back();
+      ctx->free_slots.pop_back();
+    } else {
+      if (hipEventCreate(&s.start) != hipSuccess) return -1;
+      if (hipEventCreate(&s.stop) != hipSuccess) return -1;
+    }
+  }
+  s.kernel = kernel;
+  hipEventRecord(s.start, ctx->stream);
+  ctx->pending.push_back(s);
+  return (int)ctx->pending.size() - 1;
+}
+
+void timing_end(admm_ctx *ctx, int slot) { hipEventRecord(ctx->pending[slot].stop, ctx->stream); }
+
+int timing_flush(admm_ctx *ctx) {
+  if (ctx->pending.empty()) return ADMM_OK;
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (auto &s : ctx->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
+      ctx->k_ms[s.kernel] += ms;
+      ctx->k_launches[s.kernel] += 1;
+    }
+    ctx->free_slots.push_back(s);
+  }
+  ctx->pending.clear();
+  return ADMM_OK;
+}
+
+// ---- reductions ---------------------------------------------------------------------------
+
+// One block sums each scalar's partials in a fixed tree order: deterministic for a given grid.
+__global__ void __launch_bounds__(256) k_finish_partials(const double *partials, int nblocks,
+                                                         double *scalars) {
+  __shared__ double sh[256];
+  const int s = blockIdx.x;
+  double acc = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partials[(size_t)s * kMaxPartialBlocks + i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scalars[s] = sh[0];
+}
+
+int finish_partials(admm_ctx *ctx, int nscalars, int nblocks) {
+  hipLaunchKernelGGL(k_finish_partials, dim3(nscalars), dim3(256), 0, ctx->stream,
+                     ctx->d_partials, nblocks, ctx->d_scalars);
+  ADMM_HIP_CHECK(hipGetLastError());
+  ADMM_HIP_CHECK(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * nscalars,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ADMM_OK;
+}
+
+__device__ inline double block_sum_256(double v, double *sh) {
+  // wave reduce (64 lanes), then 4 waves through LDS
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- elementwise kernels -------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_payload(const float *__restrict__ x,
+                                                 const float *__restrict__ y, float rho,
+                                                 float *__restrict__ out, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    out[i] = x[i] * rho + y[i];
+}
+
+__device__ inline float soft_threshold(float s, float l1) {
+  if (l1 > 0.0f) {
+    if (s > l1) return s - l1;
+    if (s < -l1) return s + l1;
+    return 0.0f;
+  }
+  return s;
+}
+
+__global__ void __launch_bounds__(256) k_global_update(const float *__restrict__ sum, float denom,
+                                                       float l1, float *__restrict__ z,
+                                                       uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    z[i] = soft_threshold(sum[i], l1) / denom;
+}
+
+__global__ void __launch_bounds__(256) k_dual_update(float *__restrict__ y,
+                                                     const float *__restrict__ x,
+                                                     const float *__restrict__ z, float rho,
+                                                     uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    y[i] += rho * (x[i] - z[i]);
+}
+
+// z-update + dual update + both residual partial sums in one pass over the dim-sized vectors.
+__global__ void __launch_bounds__(256) k_consensus(const float *__restrict__ sum, float denom,
+                                                   float l1, float rho,
+                                                   const float *__restrict__ x,
+                                                   float *__restrict__ y, float *__restrict__ z,
+                                                   uint64_t n, double *__restrict__ partials) {
+  __shared__ double sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double r2 = 0, s2 = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float zo = z[i];
+    const float zn = soft_threshold(sum[i], l1) / denom;
+    const float xi = x[i];
+    z[i] = zn;
+    y[i] += rho * (xi - zn);
+    const double d = (double)xi - (double)zn, e = (double)zn - (double)zo;
+    r2 += d * d;
+    s2 += e * e;
+  }
+  r2 = block_sum_256(r2, sh);
+  s2 = block_sum_256(s2, sh);
+  if (threadIdx.x == 0) {
+    partials[0 * kMaxPartialBlocks + blockIdx.x] = r2;
+    partials[1 * kMaxPartialBlocks + blockIdx.x] = s2;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dot(const float *__restrict__ a,
+                                             const float *__restrict__ b, uint64_t n,
+                                             double *__restrict__ partials) {
+  __shared__ double sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    acc += (double)a[i] * (double)b[i];
+  acc = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_axpy(float *__restrict__ y, float a,
+                                              const float *__restrict__ x, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+}
+
+__global__ void __launch_bounds__(256) k_scale(float *__restrict__ y, float a, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] *= a;
+}
+
+__global__ void __launch_bounds__(256) k_lincomb(float *__restrict__ out,
+                                                 const float *__restrict__ a, float s,
+                                                 const float *__restrict__ b, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    out[i] = a[i] + s * b[i];
+}
+
+static inline int ew_grid(admm_ctx *ctx, uint64_t n) { return grid_for(n, 256, ctx->cu_count * 8); }
+
+int vec_dot(admm_ctx *ctx, const float *a, const float *b, uint64_t n, double *out_host) {
+  const int grid = ew_grid(ctx, n);
+  hipLaunchKernelGGL(k_dot, dim3(grid), dim3(256), 0, ctx->stream, a, b, n, ctx->d_partials);
+  ADMM_HIP_CHECK(hipGetLastError());
+  ADMM_TRY(finish_partials(ctx, 1, grid));
+  *out_host = ctx->h_scalars[0];
+  return ADMM_OK;
+}
+
+int vec_axpy(admm_ctx *ctx, float *y, float a, const float *x, uint64_t n) {
+  hipLaunchKernelGGL(k_axpy, dim3(ew_grid(ctx, n)), dim3(256), 0, ctx->stream, y, a, x, n);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
+int vec_scale(admm_ctx *ctx, float *y, float a, uint64_t n) {
+  hipLaunchKernelGGL(k_scale, dim3(ew_grid(ctx, n)), dim3(256), 0, ctx->stream, y, a, n);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
+int vec_lincomb(admm_ctx *ctx, float *out, const float *a, float s, const float *b, uint64_t n) {
+  hipLaunchKernelGGL(k_lincomb, dim3(ew_grid(ctx, n)), dim3(256), 0, ctx->stream, out, a, s, b, n);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
+int vec_sub(admm_ctx *ctx, float *out, const float *a, const float *b, uint64_t n) {
+  return vec_lincomb(ctx, out, a, -1.0f, b, n);
+}
+
+}  // namespace admm_impl
+
+using namespace admm_impl;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+extern "C" const char *admm_last_error(void) { return g_last_error.c_str(); }
+extern "C" int admm_abi_version(void) { return 1; }
+
+extern "C" int admm_ctx_create(int device, void *stream, admm_ctx **out) {
+  ADMM_REQUIRE(out != nullptr, "admm_ctx_create: out is NULL");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("admm_ctx_create: no HIP device visible (%s); this library has no CPU path",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return ADMM_ERR_HIP;
+  }
+  ADMM_REQUIRE(device >= 0 && device < ndev, "admm_ctx_create: device %d out of range (%d)", device,
+               ndev);
+  ADMM_HIP_CHECK(hipSetDevice(device));
+  admm_ctx *ctx = new admm_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      set_error("admm_ctx_create: hipStreamCreate failed");
+      delete ctx;
+      return ADMM_ERR_HIP;
+    }
+    ctx->own_stream = true;
+  }
+  if (hipMalloc(&ctx->d_partials, sizeof(double) * kPartialScalars * kMaxPartialBlocks) != hipSuccess ||
+      hipMalloc(&ctx->d_scalars, sizeof(double) * kPartialScalars) != hipSuccess ||
+      hipHostMalloc(&ctx->h_scalars, sizeof(double) * kPartialScalars) != hipSuccess) {
+    set_error("admm_ctx_create: scratch allocation failed");
+    admm_ctx_destroy(ctx);
+    return ADMM_ERR_NOMEM;
+  }
+  *out = ctx;
+  return ADMM_OK;
+}
+
+extern "C" int admm_ctx_destroy(admm_ctx *ctx) {
+  if (!ctx) return ADMM_OK;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  for (auto &s : ctx->pending) {
+    hipEventDestroy(s.start);
+    hipEventDestroy(s.stop);
+  }
+  for (auto &s : ctx->free_slots) {
+    hipEventDestroy(s.start);
+    hipEventDestroy(s.stop);
+  }
+  comm_release(ctx);
+  if (ctx->d_partials) hipFree(ctx->d_partials);
+  if (ctx->d_scalars) hipFree(ctx->d_scalars);
+  if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
+  if (ctx->lbfgs_ws) hipFree(ctx->lbfgs_ws);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ADMM_OK;
+}
+
+extern "C" int admm_sync(admm_ctx *ctx) {
+  ADMM_REQUIRE(ctx, "admm_sync: ctx is NULL");
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ADMM_OK;
+}
+
+extern "C" int admm_timing_enable(admm_ctx *ctx, int on) {
+  ADMM_REQUIRE(ctx, "admm_timing_enable: ctx is NULL");
+  if (!on) ADMM_TRY(timing_flush(ctx));
+  ctx->timing = on != 0;
+  return ADMM_OK;
+}
+
+extern "C" int admm_timing_reset(admm_ctx *ctx) {
+  ADMM_REQUIRE(ctx, "admm_timing_reset: ctx is NULL");
+  ADMM_TRY(timing_flush(ctx));
+  for (int k = 0; k < ADMM_K_COUNT; ++k) {
+    ctx->k_ms[k] = 0;
+    ctx->k_launches[k] = 0;
+  }
+  return ADMM_OK;
+}
+
+extern "C" int admm_timing_get(admm_ctx *ctx, int kernel, double *total_ms, uint64_t *launches) {
+  ADMM_REQUIRE(ctx && kernel >= 0 && kernel < ADMM_K_COUNT, "admm_timing_get: bad arguments");
+  ADMM_TRY(timing_flush(ctx));
+  if (total_ms) *total_ms = ctx->k_ms[kernel];
+  if (launches) *launches = ctx->k_launches[kernel];
+  return ADMM_OK;
+}
+
+// ---- vectors --------------------------------------------------------------------------------
+
+extern "C" int admm_vec_alloc(admm_ctx *ctx, uint64_t n, float **out) {
+  ADMM_REQUIRE(ctx && out && n > 0, "admm_vec_alloc: bad arguments");
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  float *p = nullptr;
+  ADMM_HIP_CHECK(hipMalloc(&p, sizeof(float) * n));
+  hipError_t e = hipMemsetAsync(p, 0, sizeof(float) * n, ctx->stream);
+  if (e != hipSuccess) {
+    hipFree(p);
+    set_error("admm_vec_alloc: memset failed: %s", hipGetErrorString(e));
+    return ADMM_ERR_HIP;
+  }
+  *out = p;
+  return ADMM_OK;
+}
+
+extern "C" int admm_vec_free(admm_ctx *ctx, float *v) {
+  ADMM_REQUIRE(ctx, "admm_vec_free: ctx is NULL");
+  if (!v) return ADMM_OK;
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ADMM_HIP_CHECK(hipFree(v));
+  return ADMM_OK;
+}
+
+extern "C" int admm_vec_zero(admm_ctx *ctx, float *v, uint64_t n) {
+  ADMM_REQUIRE(ctx && v, "admm_vec_zero: bad arguments");
+  ADMM_HIP_CHECK(hipMemsetAsync(v, 0, sizeof(float) * n, ctx->stream));
+  return ADMM_OK;
+}
+
+extern "C" int admm_vec_copy(admm_ctx *ctx, float *dst, const float *src, uint64_t n) {
+  ADMM_REQUIRE(ctx && dst && src, "admm_vec_copy: bad arguments");
+  ADMM_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  return ADMM_OK;
+}
+
+extern "C" int admm_vec_upload(admm_ctx *ctx, float *dst, const float *src_host, uint64_t n) {
+  ADMM_REQUIRE(ctx && dst && src_host, "admm_vec_upload: bad arguments");
+  ADMM_HIP_CHECK(hipMemcpyAsync(dst, src_host, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host buffer is only borrowed
+  return ADMM_OK;
+}
+
+extern "C" int admm_vec_download(admm_ctx *ctx, float *dst_host, const float *src, uint64_t n) {
+  ADMM_REQUIRE(ctx && dst_host && src, "admm_vec_download: bad arguments");
+  ADMM_HIP_CHECK(hipMemcpyAsync(dst_host, src, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ADMM_OK;
+}
+
+// ---- consensus algebra ------------------------------------------------------------------------
+
+extern "C" int admm_payload(admm_ctx *ctx, const float *x, const float *ydual, float rho, float *out,
+                            uint64_t dim) {
+  ADMM_REQUIRE(ctx && x && ydual && out && dim > 0, "admm_payload: bad arguments");
+  KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+  hipLaunchKernelGGL(k_payload, dim3(ew_grid(ctx, dim)), dim3(256), 0, ctx->stream, x, ydual, rho, out,
+                     dim);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
+extern "C" int admm_global_update(admm_ctx *ctx, const float *sum, int num_worker, float rho,
+                                  float global_var, float l1, float *z, uint64_t dim) {
+  ADMM_REQUIRE(ctx && sum && z && dim > 0 && num_worker > 0, "admm_global_update: bad arguments");
+  const float denom = num_worker * rho + global_var;  // src/master.cc:17, float arithmetic
+  KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+  hipLaunchKernelGGL(k_global_update, dim3(ew_grid(ctx, dim)), dim3(256), 0, ctx->stream, sum, denom,
+                     l1, z, dim);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
+extern "C" int admm_dual_update(admm_ctx *ctx, float *ydual, const float *x, const float *z, float rho,
+                                uint64_t dim) {
+  ADMM_REQUIRE(ctx && ydual && x && z && dim > 0, "admm_dual_update: bad arguments");
+  KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+  hipLaunchKernelGGL(k_dual_update, dim3(ew_grid(ctx, dim)), dim3(256), 0, ctx->stream, ydual, x, z,
+                     rho, dim);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
+extern "C" int admm_consensus(admm_ctx *ctx, const float *sum, int num_worker, float rho,
+                              float global_var, float l1, const float *x, float *ydual, float *z,
+                              uint64_t dim, double *r2, double *s2) {
+  ADMM_REQUIRE(ctx && sum && x && ydual && z && dim > 0 && num_worker > 0,
+               "admm_consensus: bad arguments");
+  const float denom = num_worker * rho + global_var;
+  const int grid = grid_for(dim, 256, ctx->cu_count * 8);
+  {
+    KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_consensus, dim3(grid), dim3(256), 0, ctx->stream, sum, denom, l1, rho, x,
+                       ydual, z, dim, ctx->d_partials);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  if (r2 || s2) {
+    ADMM_TRY(finish_partials(ctx, 2, grid));
+    if (r2) *r2 = ctx->h_scalars[0];
+    if (s2) *s2 = (double)rho * (double)rho * ctx->h_scalars[1];
+  }
+  return ADMM_OK;
+}

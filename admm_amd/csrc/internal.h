@@ -1,0 +1,156 @@
+// Shared internals of libadmm_hip.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "admm_hip.h"
+
+namespace admm_impl {
+
+void set_error(const char *fmt, ...);
+
+#define ADMM_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      ::admm_impl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+                             __FILE__, __LINE__);                                         \
+      return e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;                   \
+    }                                                                                     \
+  } while (0)
+
+#define ADMM_REQUIRE(cond, ...)               \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::admm_impl::set_error(__VA_ARGS__);    \
+      return ADMM_ERR_INVALID;                \
+    }                                         \
+  } while (0)
+
+#define ADMM_TRY(expr)          \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != ADMM_OK) return rc_; \
+  } while (0)
+
+constexpr int kMaxPartialBlocks = 4096;  // reduction partial slots per output scalar
+constexpr int kPartialScalars = 8;       // scalars a reducing kernel may emit
+
+struct TimingSlot {
+  hipEvent_t start, stop;
+  int kernel;
+};
+
+}  // namespace admm_impl
+
+struct admm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int cu_count = 256;
+  // reduction scratch: kPartialScalars x kMaxPartialBlocks doubles on the device, plus a pinned
+  // host mirror for the final few scalars
+  double *d_partials = nullptr;
+  double *d_scalars = nullptr;  // kPartialScalars doubles (deterministic final sums)
+  double *h_scalars = nullptr;  // pinned
+  // timing
+  bool timing = false;
+  std::vector<admm_impl::TimingSlot> pending;
+  std::vector<admm_impl::TimingSlot> free_slots;
+  double k_ms[ADMM_K_COUNT] = {0, 0, 0, 0};
+  uint64_t k_launches[ADMM_K_COUNT] = {0, 0, 0, 0};
+  // L-BFGS workspace (lazily sized)
+  float *lbfgs_ws = nullptr;
+  uint64_t lbfgs_ws_floats = 0;
+  // RCCL
+  void *comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+struct admm_csr {
+  admm_ctx *ctx = nullptr;
+  uint64_t nrows = 0, nnz = 0, dim = 0;
+  bool has_bias = false;      // column 0 is the all-ones bias column (present in every row)
+  bool has_dup_cols = false;  // some row stores a column twice
+  uint64_t *d_rowptr = nullptr;
+  uint32_t *d_col = nullptr;
+  float *d_val = nullptr;  // nullptr = implicit 1
+  float *d_label = nullptr;
+  float *d_rowbuf = nullptr;  // nrows floats: p / residual / per-row gradient scale
+  uint32_t fwd_lpr = 16;      // lanes per row of the forward sweep
+  // transposed (column-block) copy
+  bool has_t = false;
+  uint64_t panel_rows = 0;
+  uint32_t col_block = 0, nblocks = 0;
+  uint64_t npanels = 0, tnnz = 0;
+  uint64_t *d_tptr = nullptr;  // npanels*nblocks + 1
+  uint32_t *d_trow = nullptr;
+  uint16_t *d_tcol = nullptr;
+  float *d_tval = nullptr;  // nullptr when d_val is
+  std::vector<uint64_t> h_tptr;
+  // per-coordinate accumulators for the transposed sweep (dim floats each) + touched bitmap
+  float *d_g1 = nullptr, *d_g2 = nullptr;
+  uint32_t *d_mask = nullptr;
+};
+
+namespace admm_impl {
+
+// RAII-less helpers -------------------------------------------------------------------------
+int timing_begin(admm_ctx *ctx, int kernel);  // returns slot index or -1
+void timing_end(admm_ctx *ctx, int slot);
+int timing_flush(admm_ctx *ctx);
+
+struct KernelTimer {
+  admm_ctx *ctx;
+  int slot;
+  KernelTimer(admm_ctx *c, int kernel) : ctx(c), slot(c->timing ? timing_begin(c, kernel) : -1) {}
+  ~KernelTimer() {
+    if (slot >= 0) timing_end(ctx, slot);
+  }
+};
+
+// sums `nscalars` rows of `nblocks` partials (row-major [scalar][block]) into ctx->d_scalars in
+// a fixed order, copies them to ctx->h_scalars and synchronises the stream
+int finish_partials(admm_ctx *ctx, int nscalars, int nblocks);
+
+int ensure_rowbuf(admm_csr *csr);
+int ensure_taccum(admm_csr *csr);
+
+// sweeps (sweep.hip)
+enum FwdMode { FWD_EVAL = 0, FWD_LBFGS = 1, FWD_FTRL = 2 };
+struct FwdResult {
+  double s0, s1, s2;
+};
+// margins over rows [r0, r1) with up to 4 summed weight vectors; writes csr->d_rowbuf[r]
+// (or out_rows when given) and returns mode-dependent sums through ctx->h_scalars[0..2]
+// (after finish_partials; the caller decides when to read them).
+int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w,
+                   int nw, float *out_rows, int *nblocks_out);
+// transposed sweep over panels [p0, p1): accumulates into csr->d_g1 (and d_g2 / d_mask in FTRL
+// mode), which must be zero on entry
+int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1);
+
+// vector helpers (ctx.hip)
+int vec_dot(admm_ctx *ctx, const float *a, const float *b, uint64_t n, double *out_host);
+int vec_axpy(admm_ctx *ctx, float *y, float a, const float *x, uint64_t n);         // y += a x
+int vec_scale(admm_ctx *ctx, float *y, float a, uint64_t n);                        // y *= a
+int vec_lincomb(admm_ctx *ctx, float *out, const float *a, float s, const float *b,
+                uint64_t n);  // out = a + s b
+int vec_sub(admm_ctx *ctx, float *out, const float *a, const float *b, uint64_t n);
+void comm_release(admm_ctx *ctx);  // comm.hip
+
+inline int grid_for(uint64_t work_items, int block, int max_blocks) {
+  uint64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (uint64_t)max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+}  // namespace admm_impl

@@ -1,0 +1,223 @@
+"""Host-side mirror of the reference's ADMM classes on top of the C ABI (Python flavour; the C++
+flavour used by the admm / ftrl / evan programs lives in admm_amd/host/).
+
+Names, argument meaning and call order follow src/workers.{h,cc}, src/master.{h,cc},
+src/config.h, src/arg_parser.{h,cc} and the main loop of src/admm_allreduce.cpp of the reference;
+all arithmetic happens in libadmm_hip.so on the GPU.
+"""
+import numpy as np
+
+from . import capi
+
+
+class AdmmConfig:
+    """src/config.h:11-34 plus the keys this build adds (all optional in a conf file):
+    global_l1 (soft threshold of the consensus update, 0 = the reference's ridge update),
+    local_solver (ftrl | lbfgs), ftrl_batch, lbfgs_* ."""
+
+    def __init__(self):
+        self.step_size = 0.0
+        self.global_var = 0.0
+        self.bias_var = 0.0
+        self.ftrl_alpha = 0.0
+        self.dim = 0
+        self.passes = 0
+        self.train_path = ""
+        self.test_path = ""
+        self.output_path = ""
+        self.global_l1 = 0.0
+        self.local_solver = "ftrl"
+        self.ftrl_batch = 1
+        self.lbfgs = dict(m=6, max_iter=10, max_linesearch=20, epsilon=1e-5, ftol=1e-4, wolfe=0.9)
+
+
+class FtrlConfig:
+    """src/config.h:36-58"""
+
+    def __init__(self, admm_params=None):
+        self.alpha = admm_params.ftrl_alpha if admm_params else 0.0
+        self.beta = 1.0 if admm_params else 0.0
+        self.l_1 = 0.0
+        self.l_2 = 0.0
+        self.dim = admm_params.dim if admm_params else 0
+        self.passes = 0
+        self.train_path = self.test_path = self.output_path = ""
+
+
+def _tokens(path):
+    with open(path) as f:
+        return f.read().split()
+
+
+class ArgParser:
+    """src/arg_parser.cc:10-90: whitespace-separated tokens; `key = value` fills the dictionary,
+    `psid : num_part` appends one worker line (rank r uses line r)."""
+
+    def __init__(self):
+        self.psid, self.num_part, self.load_path = [], [], ""
+
+    def _parse(self, path):
+        d = {}
+        try:
+            tok = _tokens(path)
+        except OSError:
+            print("config file open failed. ")
+            return d
+        i = 0
+        while i + 1 < len(tok):
+            key, val = tok[i], tok[i + 1]
+            i += 2
+            if val == "=" and i < len(tok):
+                d[key] = tok[i]
+                i += 1
+            elif val == ":" and i < len(tok):
+                self.psid.append(key)
+                self.num_part.append(_atoi(tok[i]))
+                i += 1
+        return d
+
+    def ADMMParse(self, path, admm_params):
+        d = self._parse(path)
+        admm_params.step_size = np.float32(_atof(d.get("step_size", "")))
+        admm_params.bias_var = np.float32(_atof(d.get("bias_var", "")))
+        admm_params.global_var = np.float32(_atof(d.get("global_var", "")))
+        admm_params.ftrl_alpha = np.float32(_atof(d.get("ftrl_alpha", "")))
+        admm_params.passes = _atoi(d.get("passes", ""))
+        admm_params.dim = _atoi(d.get("dim", ""))
+        # optional keys of this build
+        for k in ("train_path", "test_path", "output_path"):
+            if k in d:
+                setattr(admm_params, k, d[k])
+        if "global_l1" in d:
+            admm_params.global_l1 = np.float32(_atof(d["global_l1"]))
+        if "local_solver" in d:
+            admm_params.local_solver = d["local_solver"]
+        if "ftrl_batch" in d:
+            admm_params.ftrl_batch = max(1, _atoi(d["ftrl_batch"]))
+        for k in ("m", "max_iter", "max_linesearch"):
+            if "lbfgs_" + k in d:
+                admm_params.lbfgs[k] = _atoi(d["lbfgs_" + k])
+        for k in ("epsilon", "ftol", "wolfe"):
+            if "lbfgs_" + k in d:
+                admm_params.lbfgs[k] = _atof(d["lbfgs_" + k])
+        if "load_path" in d:
+            self.load_path = d["load_path"]
+
+    def FTRLParse(self, path, ftrl_params):
+        d = self._parse(path)
+        ftrl_params.train_path = d.get("train_path", "")
+        ftrl_params.test_path = d.get("test_path", "")
+        ftrl_params.output_path = d.get("output_path", "")
+        ftrl_params.alpha = np.float32(_atof(d.get("ftrl_alpha", "")))
+        ftrl_params.beta = np.float32(_atof(d.get("ftrl_beta", "")))
+        ftrl_params.l_1 = np.float32(_atof(d.get("l_1", "")))
+        ftrl_params.l_2 = np.float32(_atof(d.get("l_2", "")))
+        ftrl_params.passes = _atoi(d.get("passes", ""))
+        ftrl_params.dim = _atoi(d.get("dim", ""))
+        if "load_path" in d:
+            self.load_path = d["load_path"]
+
+
+def _atof(s):
+    """C atof: longest valid numeric prefix, 0 when there is none."""
+    import re
+    m = re.match(r"\s*[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?)", s or "")
+    return float(m.group(0)) if m else 0.0
+
+
+def _atoi(s):
+    import re
+    m = re.match(r"\s*[+-]?\d+", s or "")
+    return int(m.group(0)) if m else 0
+
+
+class Worker:
+    """src/workers.h:16-82.  base_vec_ (x), bias_vec_, langr_vec_ (y), nt_vec_, zt_vec_ are device
+    vectors; the global weights z live in the caller's `global_weights` device vector."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.psid_, self.num_part_, self.partid_ = "", 1, 0
+        self.load = False
+
+    def InitWorker(self, fdim):
+        c = self.ctx
+        self.dim = int(fdim)
+        self.base_vec_ = c.vec(fdim)
+        self.bias_vec_ = c.vec(fdim)
+        self.langr_vec_ = c.vec(fdim)
+        self.nt_vec_ = c.vec(fdim)
+        self.zt_vec_ = c.vec(fdim)
+        # FTRL solver state of one x-update (FtrlSolver weight_/mid_weight_/squared_sum_)
+        self._n = c.vec(fdim)
+        self._z = c.vec(fdim)
+        self.load = False
+
+    def BaseUpdate(self, train_parts, admm_params, global_weights):
+        """src/workers.cc:51-87.  train_parts: the worker's data parts as capi.SampleSet."""
+        if admm_params.local_solver == "lbfgs":
+            assert len(train_parts) == 1, "the L-BFGS local solver takes one resident part"
+            return train_parts[0].lbfgs_solve(self.base_vec_, offset=None, z=global_weights,
+                                              ydual=self.langr_vec_, rho=admm_params.step_size,
+                                              **admm_params.lbfgs)
+        # FtrlSolver::Init zeroes w; z, n start from zt_vec_, nt_vec_ (src/workers.cc:64-67)
+        self.base_vec_.zero()
+        self._n.copy_from(self.nt_vec_)
+        self._z.copy_from(self.zt_vec_)
+        for part in train_parts:  # src/workers.cc:73-77, l_2 = 200, l_1 = 1, beta = 1
+            part.ftrl_pass(self.base_vec_, self._z, self._n, self.bias_vec_, global_weights,
+                           admm_params.ftrl_alpha, 1.0, 1.0, 200.0, batch=admm_params.ftrl_batch)
+        if self.load:  # src/workers.cc:81-85
+            self.nt_vec_.copy_from(self._n)
+            self.zt_vec_.copy_from(self._z)
+            self.load = False
+        return dict(evals=len(train_parts))
+
+    def LangrangeUpdate(self, admm_params, global_weights):
+        """src/workers.cc:115-119"""
+        self.ctx.dual_update(self.langr_vec_, self.base_vec_, global_weights, admm_params.step_size)
+
+    def GetWeights(self, admm_params, out):
+        """src/workers.cc:121-125"""
+        self.ctx.payload(self.base_vec_, self.langr_vec_, admm_params.step_size, out)
+
+
+class Master:
+    """src/master.h:12-17"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def GlobalUpdate(self, workers_sum, admm_params, global_weights, num_worker):
+        self.ctx.global_update(workers_sum, num_worker, admm_params.step_size, admm_params.global_var,
+                               admm_params.global_l1, global_weights)
+        return True
+
+
+def admm_iteration(worker, master, train_parts, test_set, admm_params, global_weights, tmp,
+                   allreduce, world, last, fused_consensus=True):
+    """One trip of the loop in src/admm_allreduce.cpp:55-91 for one rank.
+    `allreduce(tmp)` sums the payload over ranks in place (rabit::Allreduce<op::Sum>, :69)."""
+    if last:
+        worker.load = True                                        # :60-61
+    stats = worker.BaseUpdate(train_parts, admm_params, global_weights)   # :66
+    worker.GetWeights(admm_params, tmp)                           # :67
+    allreduce(tmp)                                                # :69
+    line = None
+    if test_set is not None:                                      # :76-81
+        loss, auc, n = test_set.metrics([worker.base_vec_, worker.bias_vec_])
+        line = (loss, auc, n)
+    if fused_consensus:                                           # :84-85 in one kernel
+        r2, s2 = worker.ctx.consensus(tmp, world, admm_params.step_size, admm_params.global_var,
+                                      admm_params.global_l1, worker.base_vec_, worker.langr_vec_,
+                                      global_weights)
+    else:
+        master.GlobalUpdate(tmp, admm_params, global_weights, world)
+        worker.LangrangeUpdate(admm_params, global_weights)
+        r2 = s2 = None
+    return dict(line=line, r2=r2, s2=s2, stats=stats)
+
+
+def format_line(psid, loss, auc, n):
+    """the per-iteration report of src/admm_allreduce.cpp:79"""
+    return "%s | %.7f | %.7f | %d" % (psid, loss, auc, n)

@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Throughput of one ADMM iteration of the sparse logistic-regression hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2] at N=1, configs[3] at N=8): ADMM-LR with the L1+L2 consensus
+update on a synthetic power-law set of 100M rows x 2^22 features, ~100 stored entries per row,
+row-sharded over the N GPUs (the same 100M rows for every N: strong scaling).  One step = one
+ADMM iteration on every rank: local x-update (L-BFGS on logistic loss + y.(x-z) + rho/2|x-z|^2,
+every objective/gradient evaluation = one forward CSR sweep + one transposed sweep over the
+rank's shard), payload rho*x+y, sum all-reduce over ranks (RCCL through torch.distributed),
+logloss/AUC on the rank's test shard, fused consensus + dual update.
+
+value = stored entries swept per second, whole job: sum over ranks of
+        (shard nnz incl. the bias column) x (objective/gradient evaluations in the K steps) / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="total rows over all ranks")
+    ap.add_argument("--dim", type=int, default=1 << 22)
+    ap.add_argument("--mean-nnz", type=float, default=99.0, help="raw features per row (bias adds 1)")
+    ap.add_argument("--lbfgs-iters", type=int, default=3)
+    ap.add_argument("--panel-rows", type=int, default=1 << 20)
+    ap.add_argument("--col-block", type=int, default=16384)
+    ap.add_argument("--test-frac", type=float, default=0.01)
+    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20251111)
+    return ap.parse_args()
+
+
+def cpu_baseline(ctx, args, rho):
+    """The CPU restatement (oracle, one thread) on a bounded sample of the same workload: the same
+    generator, the same objective/gradient evaluation, timed on this machine's host cores."""
+    from oracle import oracle as orc
+    orc.build()
+    n = args.cpu_sample_rows
+    dev = ctx.csr_synth(n, args.dim, args.mean_nnz, seed=args.seed, row_offset=0)
+    csr = orc.Csr(*dev.download(), args.dim)
+    dev.destroy()
+    x = np.zeros(args.dim, np.float32)
+    z = np.zeros(args.dim, np.float32)
+    y = np.zeros(args.dim, np.float32)
+    orc.logistic_fg(csr, args.dim, x, None, z, y, rho)          # warm caches / page in
+    evals, t0 = 0, time.perf_counter()
+    while True:
+        f, g = orc.logistic_fg(csr, args.dim, x, None, z, y, rho)
+        x = (x - np.float32(1e-4) * g.astype(np.float32)).astype(np.float32)
+        evals += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or evals >= 8:
+            break
+    fg_rate = csr.nnz * evals / dt
+    # the reference's own local solver on the same sample: one sequential FTRL pass
+    w, zz, nn, off = (np.zeros(args.dim, np.float32) for _ in range(4))
+    t0 = time.perf_counter()
+    orc.ftrl_run(csr, w, zz, nn, off, z, 0.1, 1.0, 1.0, 200.0)
+    ftrl_rate = csr.nnz / (time.perf_counter() - t0)
+    return {"value": fg_rate, "unit": "nnz/s", "cores": 1, "kind": "port",
+            "sample": "%d rows / %d nnz of the same generator; %d objective+gradient evaluations of "
+                      "oracle/admm_oracle.c (gcc -O2, 1 thread)" % (n, csr.nnz, evals),
+            "ftrl_pass_nnz_per_s": ftrl_rate}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from admm_amd import capi, driver
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # one HIP stream for the library's kernels and for torch's collectives
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    ctx = capi.Context(local_rank, stream=tstream.cuda_stream)
+
+    # ---- the rank's shard -------------------------------------------------------------------
+    rows_total = args.rows
+    r0 = rows_total * rank // world
+    r1 = rows_total * (rank + 1) // world
+    t_gen = time.perf_counter()
+    train = ctx.csr_synth(r1 - r0, args.dim, args.mean_nnz, seed=args.seed, row_offset=r0)
+    train.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
+    n_test = max(1, int((r1 - r0) * args.test_frac))
+    test = ctx.csr_synth(n_test, args.dim, args.mean_nnz, seed=args.seed + 1, row_offset=r0)
+    ctx.sync()
+    t_gen = time.perf_counter() - t_gen
+
+    prm = driver.AdmmConfig()
+    prm.step_size, prm.global_var, prm.global_l1 = 0.01, 4.0, 0.01     # script/start.sh:25-27
+    prm.dim, prm.local_solver = args.dim, "lbfgs"
+    prm.lbfgs.update(max_iter=args.lbfgs_iters)
+    worker = driver.Worker(ctx)
+    worker.InitWorker(args.dim)
+    master = driver.Master(ctx)
+    zg = ctx.vec(args.dim)
+    payload_t = torch.zeros(args.dim, dtype=torch.float32, device="cuda")
+    payload = capi.DeviceVec.from_ptr(ctx, payload_t.data_ptr(), args.dim)
+
+    def allreduce(_buf):
+        if world > 1:
+            dist.all_reduce(payload_t, op=dist.ReduceOp.SUM)
+
+    def step(last=False):
+        return driver.admm_iteration(worker, master, [train], test, prm, zg, payload, allreduce,
+                                     world, last)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    evals = 0
+    t0 = time.perf_counter()
+    last_rec = None
+    for _ in range(args.steps):
+        last_rec = step()
+        evals += last_rec["stats"]["evals"]
+    barrier()
+    dt = time.perf_counter() - t0
+    fwd_ms, fwd_n = ctx.timing_get(capi.K_FORWARD)
+    tr_ms, tr_n = ctx.timing_get(capi.K_TRANSPOSED)
+    ctx.timing_enable(False)
+
+    # max time and total swept entries over ranks
+    swept = float(train.nnz) * evals
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([swept, float(train.nnz), float(evals)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        swept, nnz_total, evals_total = (float(v) for v in s.tolist())
+    else:
+        nnz_total, evals_total = float(train.nnz), float(evals)
+
+    if rank == 0:
+        rows = r1 - r0
+        # algorithmic HBM bytes of one launch over this rank's shard (idx u32 + val f32 per stored
+        # entry; rowptr 8 + label 4 + residual 4 per row forward, residual 4 per row transposed;
+        # one dim-sized vector each)
+        tnnz = train.nnz - rows                       # the bias column is reduced by the forward sweep
+        fwd_bytes = 8.0 * train.nnz + 16.0 * rows + 4.0 * args.dim
+        tr_bytes = 8.0 * tnnz + 4.0 * rows + 4.0 * args.dim
+        fwd_avg = fwd_ms / max(fwd_n, 1) * 1e-3
+        tr_avg = tr_ms / max(tr_n, 1) * 1e-3
+        # the forward sweep also runs once per step on the test shard: count train-shard launches
+        kernels = {
+            "forward_csr_sweep": {"avg_ms": fwd_avg * 1e3, "launches": fwd_n,
+                                  "note": "average includes the small test-shard launch of each step"},
+            "transposed_block_sweep": {"avg_ms": tr_avg * 1e3, "launches": tr_n,
+                                       "achieved_GBs": tr_bytes / tr_avg / 1e9 if tr_avg > 0 else None},
+        }
+        # per-launch figure for the forward sweep over the train shard only
+        test_rows_frac = float(test.nnz) / float(train.nnz)
+        fwd_train_launches = evals
+        if fwd_n > 0 and fwd_train_launches > 0:
+            fwd_train_avg = (fwd_ms * 1e-3) / (fwd_train_launches + args.steps * test_rows_frac)
+        else:
+            fwd_train_avg = 0.0
+        kernels["forward_csr_sweep"]["train_launch_ms"] = fwd_train_avg * 1e3
+        kernels["forward_csr_sweep"]["achieved_GBs"] = fwd_bytes / fwd_train_avg / 1e9 if fwd_train_avg else None
+        if tr_ms >= fwd_ms:
+            dom, ach = "transposed_block_sweep", tr_bytes / tr_avg / 1e9
+        else:
+            dom, ach = "forward_csr_sweep", fwd_bytes / fwd_train_avg / 1e9
+        out = {
+            "metric": "nnz/sec per ADMM iteration + % HBM roofline at 1/2/4/8 MI355X",
+            "value": swept / dt,
+            "unit": "nnz/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "ADMM-LR L1+L2, synthetic %d rows x %d features, ~%d nnz/row, row-sharded over %d GPU(s)"
+                            % (rows_total, args.dim, round(args.mean_nnz) + 1, world),
+                "local_solver": "lbfgs (max_iter %d)" % args.lbfgs_iters,
+                "rows_total": rows_total, "dim": args.dim, "nnz_total": nnz_total,
+                "objective_gradient_evals_total": evals_total,
+                "admm_iterations_per_s": args.steps / dt,
+                "generate_and_build_s": t_gen,
+                "last_line": driver.format_line("rank0", *last_rec["line"]) if last_rec and last_rec["line"] else None,
+                "last_residuals": [last_rec["r2"], last_rec["s2"]] if last_rec else None,
+            },
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernels": kernels},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, args, float(prm.step_size))
+        print(json.dumps(out), flush=True)
+
+    train.destroy()
+    test.destroy()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

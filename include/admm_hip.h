@@ -1,0 +1,195 @@
+/*
+ * admm_hip.h -- C ABI of libadmm_hip.so: the ADMM / FTRL sparse logistic-regression hot path on
+ * MI355X (gfx950).  Plain C, opaque handles, plain pointers and sizes.
+ *
+ * Every entry point names the reference interface it stands in for (paths relative to the
+ * wuyunhao/admm tree).  The reference has no FFI layer of its own: its seam is the C++ class
+ * surface of src/ (SampleSet, FtrlSolver, Worker, Master, Metrics), which the host classes under
+ * admm_amd/host/ rebuild on top of these calls.
+ *
+ * Conventions
+ *   - return value 0 = success, negative = ADMM_ERR_*; admm_last_error() gives the message of
+ *     the calling thread's last failure.  No exceptions cross the boundary.
+ *   - one host thread per context; work is queued on the context's HIP stream; calls that
+ *     return a host scalar synchronise that stream, all others are asynchronous.
+ *   - `float *` vector arguments are DEVICE pointers of `dim` floats unless the name says host.
+ *   - there is no CPU implementation behind these calls: without a GPU they fail.
+ */
+#ifndef ADMM_HIP_H_
+#define ADMM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADMM_OK 0
+#define ADMM_ERR_INVALID (-1) /* bad argument / shape mismatch */
+#define ADMM_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define ADMM_ERR_NOMEM (-3)
+#define ADMM_ERR_STATE (-4) /* e.g. transposed copy not built */
+#define ADMM_ERR_COMM (-5)  /* RCCL missing or failed */
+
+typedef struct admm_ctx admm_ctx; /* one GPU + one stream */
+typedef struct admm_csr admm_csr; /* one sample set resident in HBM */
+
+const char *admm_last_error(void);
+int admm_abi_version(void);
+
+/* ---- context ----------------------------------------------------------------------------- */
+
+/* Stands in for rabit::Init / rabit::Finalize as far as device set-up goes
+ * (src/admm_allreduce.cpp:9,113).  `stream` is a hipStream_t to queue on, or NULL to let the
+ * library create its own. */
+int admm_ctx_create(int device, void *stream, admm_ctx **out);
+int admm_ctx_destroy(admm_ctx *ctx);
+int admm_sync(admm_ctx *ctx);
+
+/* Per-kernel device timing with HIP events on the context's stream (profiling aid, no
+ * counterpart in the reference).  kernel ids: ADMM_K_*. */
+#define ADMM_K_FORWARD 0    /* row-parallel CSR sweep (margins, sigmoid, loss) */
+#define ADMM_K_TRANSPOSED 1 /* column-block sweep (X^T r) */
+#define ADMM_K_FTRL_SEQ 2   /* exact sequential FTRL pass */
+#define ADMM_K_ELEMENTWISE 3
+#define ADMM_K_COUNT 4
+int admm_timing_enable(admm_ctx *ctx, int on);
+int admm_timing_reset(admm_ctx *ctx);
+int admm_timing_get(admm_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
+
+/* ---- dim-sized vectors (Worker::InitWorker, src/workers.cc:32-46) ------------------------- */
+
+int admm_vec_alloc(admm_ctx *ctx, uint64_t n, float **out); /* zero-filled */
+int admm_vec_free(admm_ctx *ctx, float *v);
+int admm_vec_zero(admm_ctx *ctx, float *v, uint64_t n);
+int admm_vec_copy(admm_ctx *ctx, float *dst, const float *src, uint64_t n);
+int admm_vec_upload(admm_ctx *ctx, float *dst, const float *src_host, uint64_t n);
+int admm_vec_download(admm_ctx *ctx, float *dst_host, const float *src, uint64_t n);
+
+/* ---- sample sets (SampleSet, src/sample_set.cc:13-92) ------------------------------------- */
+
+/* SampleSet::Initialize + TranslateData: copy a parsed row block (host arrays, borrowed for the
+ * call) into HBM as CSR: rowptr u64[nrows+1], col u32[nnz], val f32[nnz] (NULL = implicit 1, as
+ * dmlc::Row with value == NULL), label f32[nrows].  With add_bias != 0 every row gets the
+ * (index 0, value 1) entry in front and all indices move up by one, on the device
+ * (src/sample_set.cc:70-88); `dim` is the dimension AFTER that shift.  Column indices must be
+ * < dim (checked, as dmlc's SDot CHECKs).  */
+int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                    const float *label, uint64_t nrows, uint64_t nnz, uint64_t dim, int add_bias,
+                    admm_csr **out);
+
+/* Seeded synthetic power-law sample set generated on the device (no counterpart in the
+ * reference; benchmark input).  Feature ids are Zipf(zipf_s) ranks scattered over [0, dim-1) by
+ * a fixed bijection, de-duplicated and sorted inside each row; values are 1; labels are
+ * Bernoulli(sigmoid(x . w*)) for a hidden sparse w*.  Rows are numbered from row_offset so that
+ * row shards of one data set can be generated independently.  The bias column is always added. */
+typedef struct admm_synth_spec {
+  uint64_t nrows;
+  uint64_t dim;        /* including the bias column */
+  uint64_t seed;
+  uint64_t row_offset; /* global index of this shard's first row */
+  float mean_nnz;      /* mean raw features per row (before the bias entry) */
+  float zipf_s;        /* > 1 */
+  int len_dist;        /* 0: ~Poisson(mean_nnz); 1: log-normal heavy tail with the same mean */
+  float tail_sigma;    /* log-normal sigma for len_dist 1 */
+  uint32_t max_len;    /* raw row length cap, <= 1024 */
+} admm_synth_spec;
+int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_csr **out);
+
+int admm_csr_shape(const admm_csr *csr, uint64_t *nrows, uint64_t *nnz, uint64_t *dim);
+/* Copy the device CSR (after the bias shift) back to host arrays sized by admm_csr_shape. */
+int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, float *val,
+                      float *label);
+/* Build the column-block copy that the transposed sweep reads (X^T r, mini-batch FTRL):
+ * rows are cut into panels of `panel_rows`, columns into blocks of `col_block` (<= 16384),
+ * and each (panel, block) cell stores its entries contiguously.  0 picks defaults. */
+int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block);
+/* Bytes of HBM held by this sample set. */
+int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t *transposed_bytes);
+int admm_csr_destroy(admm_csr *csr);
+
+/* ---- metrics (Metrics, src/metrics.cc:45-117) --------------------------------------------- */
+
+/* Per-row P(y=1|x) with the margin summed over `ngroups` (<= 4) weight vectors and clamped to
+ * [-35, 35] (src/metrics.cc:54-58).  p_out: DEVICE buffer of nrows floats. */
+int admm_predict(admm_csr *csr, const float *const *groups, int ngroups, float *p_out);
+/* Metrics::LogLoss and Metrics::Auc (single-model form) in one call.  logloss_mean is the mean
+ * of -log p / -log(1-p) over rows with label > 0 / <= 0 (double accumulation, fixed order);
+ * auc is the tie-aware rank-sum AUC with positives = rows whose label truncates to 1, computed
+ * on the device in double.  Either output pointer may be NULL. */
+int admm_metrics(admm_csr *csr, const float *const *groups, int ngroups, double *logloss_mean,
+                 double *auc, uint64_t *nrows);
+
+/* ---- FTRL-proximal (FtrlSolver, src/ftrl.cc:36-145) --------------------------------------- */
+
+/* FtrlSolver::Run: one pass over the sample set, then one more Predict on the last row.
+ * w, z, n are the solver state (weight_, mid_weight_, squared_sum_), updated in place;
+ * offset / reg_offset as in Run's arguments.  batch == 1 is the reference's sequential
+ * semantics row by row.  batch > 1 (needs the transposed copy, panel_rows == batch) predicts
+ * all rows of a batch from the state at its start and then applies the summed update per
+ * coordinate. */
+int admm_ftrl_pass(admm_csr *csr, float *w, float *z, float *n, const float *offset,
+                   const float *reg_offset, float alpha, float beta, float l1, float l2,
+                   uint64_t batch);
+
+/* ---- batch local objective for the L-BFGS local solver (no counterpart in the reference; the
+ *      x-update of src/workers.cc:51-87 solved as a smooth problem) ------------------------- */
+
+/* f = sum_rows [softplus(m) - t m] + y^T (x - z) + rho/2 ||x - z||^2 with m = X (x + offset),
+ * g = X^T (sigmoid(m) - t) + y + rho (x - z).  offset, z, ydual may be NULL (= 0).
+ * f_out: host double.  g_out: device, dim floats.  Needs the transposed copy. */
+int admm_logistic_fg(admm_csr *csr, const float *x, const float *offset, const float *z,
+                     const float *ydual, float rho, double *f_out, float *g_out);
+
+typedef struct admm_lbfgs_params {
+  int m;              /* history pairs, default 6 */
+  int max_iter;       /* default 10 */
+  int max_linesearch; /* default 20 */
+  float epsilon;      /* ||g|| / max(1, ||x||) stop, default 1e-5 */
+  float ftol;         /* Armijo, default 1e-4 */
+  float wolfe;        /* curvature, default 0.9 */
+} admm_lbfgs_params;
+typedef struct admm_lbfgs_result {
+  double f;
+  int evals; /* objective/gradient evaluations = full sweeps of the sample set */
+  int iters;
+} admm_lbfgs_result;
+/* Minimise the objective above over x (in place) with L-BFGS (two-loop recursion, backtracking
+ * Armijo + weak Wolfe line search).  params == NULL uses the defaults. */
+int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, const float *z,
+                     const float *ydual, float rho, const admm_lbfgs_params *params,
+                     admm_lbfgs_result *result);
+
+/* ---- consensus algebra -------------------------------------------------------------------- */
+
+/* Worker::GetWeights (src/workers.cc:121-125): out_i = x_i * rho + y_i */
+int admm_payload(admm_ctx *ctx, const float *x, const float *ydual, float rho, float *out,
+                 uint64_t dim);
+/* Master::GlobalUpdate (src/master.cc:5-20): z_i = S_i / (num_worker * rho + global_var); with
+ * l1 > 0, S_i is soft-thresholded by l1 first. */
+int admm_global_update(admm_ctx *ctx, const float *sum, int num_worker, float rho,
+                       float global_var, float l1, float *z, uint64_t dim);
+/* Worker::LangrangeUpdate (src/workers.cc:115-119): y_i += rho * (x_i - z_i) */
+int admm_dual_update(admm_ctx *ctx, float *ydual, const float *x, const float *z, float rho,
+                     uint64_t dim);
+/* GlobalUpdate + LangrangeUpdate + residual norms as ONE elementwise pass:
+ * z (in: previous consensus, out: new), ydual updated in place,
+ * r2 = sum (x - z_new)^2, s2 = rho^2 sum (z_new - z_old)^2 (host doubles, may be NULL). */
+int admm_consensus(admm_ctx *ctx, const float *sum, int num_worker, float rho, float global_var,
+                   float l1, const float *x, float *ydual, float *z, uint64_t dim, double *r2,
+                   double *s2);
+
+/* ---- collective (rabit::Allreduce<op::Sum>, src/admm_allreduce.cpp:69) -------------------- */
+
+/* RCCL communicator over the context's device.  unique_id: 128 bytes from
+ * admm_comm_unique_id() on rank 0, handed to every rank by the launcher. */
+int admm_comm_unique_id(void *unique_id_128);
+int admm_comm_init(admm_ctx *ctx, int rank, int world, const void *unique_id_128);
+/* In-place fp32 sum over ranks on the context's stream (world 1 without a communicator is a
+ * no-op, as rabit's single-process mode). */
+int admm_allreduce_sum_f32(admm_ctx *ctx, float *buf, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADMM_HIP_H_ */

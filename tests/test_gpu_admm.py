@@ -1,0 +1,120 @@
+"""The ADMM outer loop on the GPU (admm_amd.driver over the C ABI) against the CPU restatement of
+src/admm_allreduce.cpp:55-91, for 1 and 3 ranks held in one process."""
+import numpy as np
+import pytest
+
+from conftest import make_synth_csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from admm_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _run_gpu(ctx, raws_train, raws_test, conf, dim):
+    from admm_amd import driver
+    nrank = len(raws_train)
+    prm = driver.AdmmConfig()
+    prm.step_size, prm.global_var, prm.ftrl_alpha = conf.step_size, conf.global_var, conf.ftrl_alpha
+    prm.passes, prm.dim, prm.global_l1 = conf.passes, dim, conf.global_l1
+    prm.local_solver, prm.ftrl_batch = conf.local_solver, conf.ftrl_batch
+    prm.lbfgs.update(conf.lbfgs)
+    workers, trains, tests, zs, tmps = [], [], [], [], []
+    for r in range(nrank):
+        w = driver.Worker(ctx)
+        w.InitWorker(dim)
+        workers.append(w)
+        t = ctx.csr_upload(raws_train[r].rowptr, raws_train[r].col, raws_train[r].val,
+                           raws_train[r].label, dim, add_bias=True)
+        if prm.local_solver == "lbfgs" or prm.ftrl_batch > 1:
+            t.build_transposed(panel_rows=prm.ftrl_batch if prm.ftrl_batch > 1 else 0, col_block=128)
+        trains.append([t])
+        tests.append(ctx.csr_upload(raws_test[r].rowptr, raws_test[r].col, raws_test[r].val,
+                                    raws_test[r].label, dim, add_bias=True))
+        zs.append(ctx.vec(dim))      # every rank holds its own replica of the global weights
+        tmps.append(ctx.vec(dim))
+    master = driver.Master(ctx)
+    records = []
+    for it in range(prm.passes):
+        last = it == prm.passes - 1
+        # phase 1 on every rank: local solve + payload
+        stats = []
+        for r in range(nrank):
+            if last:
+                workers[r].load = True
+            stats.append(workers[r].BaseUpdate(trains[r], prm, zs[r]))
+            workers[r].GetWeights(prm, tmps[r])
+        # the all-reduce: host sum in rank order, as the oracle does
+        total = np.zeros(dim, np.float32)
+        for r in range(nrank):
+            total = (total + tmps[r].download()).astype(np.float32)
+        lines, res = [], []
+        for r in range(nrank):
+            tmps[r].upload(total)
+            lines.append(tests[r].metrics([workers[r].base_vec_, workers[r].bias_vec_]))
+            res.append(ctx.consensus(tmps[r], nrank, prm.step_size, prm.global_var, prm.global_l1,
+                                     workers[r].base_vec_, workers[r].langr_vec_, zs[r]))
+        records.append(dict(total=total, z=zs[0].download(),
+                            x=[w.base_vec_.download() for w in workers],
+                            y=[w.langr_vec_.download() for w in workers],
+                            lines=lines, residuals=res, stats=stats))
+    final = dict(nt=[w.nt_vec_.download() for w in workers], zt=[w.zt_vec_.download() for w in workers])
+    for t in trains:
+        t[0].destroy()
+    for t in tests:
+        t.destroy()
+    return records, final
+
+
+def _compare(rec_gpu, rec_ref, rtol, atol, line_rel=2e-5, auc_rel=5e-5, res_rel=1e-4):
+    assert len(rec_gpu) == len(rec_ref)
+    for a, b in zip(rec_gpu, rec_ref):
+        np.testing.assert_allclose(a["total"], b["total"], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(a["z"], b["z"], rtol=rtol, atol=atol)
+        for xa, xb in zip(a["x"], b["x"]):
+            np.testing.assert_allclose(xa, xb, rtol=rtol, atol=atol)
+        for ya, yb in zip(a["y"], b["y"]):
+            np.testing.assert_allclose(ya, yb, rtol=rtol, atol=atol)
+        for (la, aa, na), (lb, ab, nb) in zip(a["lines"], b["lines"]):
+            assert na == nb
+            assert la == pytest.approx(lb, rel=line_rel)
+            assert aa == pytest.approx(ab, rel=auc_rel)
+        for (r2a, s2a), (r2b, s2b) in zip(a["residuals"], b["residuals"]):
+            assert r2a == pytest.approx(r2b, rel=res_rel, abs=1e-12)
+            assert s2a == pytest.approx(s2b, rel=res_rel, abs=1e-14)
+
+
+@pytest.mark.parametrize("nrank", [1, 3])
+def test_admm_ftrl_mode_matches_reference_loop(ctx, oracle, nrank):
+    dim = 257
+    raws_train = [make_synth_csr(1200, dim, 14, seed=50 + r) for r in range(nrank)]
+    raws_test = [make_synth_csr(300, dim, 14, seed=60 + r) for r in range(nrank)]
+    conf = oracle.AdmmConf(step_size=0.01, global_var=4.0, ftrl_alpha=0.1, passes=4, dim=dim, bias_var=0.01)
+    _, _, rec_ref = oracle.admm_run([[oracle.translate(t)] for t in raws_train],
+                                    [oracle.translate(t) for t in raws_test], conf)
+    rec_gpu, final = _run_gpu(ctx, raws_train, raws_test, conf, dim)
+    _compare(rec_gpu, rec_ref, rtol=1e-5, atol=1e-7)
+    # the FTRL state kept on the last iteration (src/workers.cc:81-85) matches too
+    wk, _, _ = oracle.admm_run([[oracle.translate(t)] for t in raws_train],
+                               [oracle.translate(t) for t in raws_test], conf)
+    for r in range(nrank):
+        np.testing.assert_allclose(final["nt"][r], wk[r].nt, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(final["zt"][r], wk[r].zt, rtol=1e-5, atol=1e-6)
+
+
+def test_admm_lbfgs_mode(ctx, oracle):
+    dim, nrank = 129, 2
+    raws_train = [make_synth_csr(900, dim, 10, seed=70 + r) for r in range(nrank)]
+    raws_test = [make_synth_csr(250, dim, 10, seed=80 + r) for r in range(nrank)]
+    conf = oracle.AdmmConf(step_size=5.0, global_var=1.0, ftrl_alpha=0.1, passes=3, dim=dim, global_l1=0.05,
+                           local_solver="lbfgs", lbfgs=dict(max_iter=100, epsilon=1e-6))
+    _, _, rec_ref = oracle.admm_run([[oracle.translate(t)] for t in raws_train],
+                                    [oracle.translate(t) for t in raws_test], conf)
+    rec_gpu, _ = _run_gpu(ctx, raws_train, raws_test, conf, dim)
+    # both local solves run to convergence; iterates agree to the solver tolerance
+    _compare(rec_gpu, rec_ref, rtol=5e-3, atol=2e-3, line_rel=1e-3, auc_rel=1e-3, res_rel=5e-2)

@@ -1,0 +1,311 @@
+"""Parity of the HIP path (through the C ABI) with the CPU restatement on the same inputs.
+
+Tolerances: index / nnz bookkeeping bit-exact; floating point 1e-5 relative (the figure the
+reference hot path is specified to), with an absolute floor for values that are sums of
+cancelling terms."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_synth_csr
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from admm_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def upload(ctx, raw, dim):
+    return ctx.csr_upload(raw.rowptr, raw.col, raw.val, raw.label, dim, add_bias=True)
+
+
+def close(a, b, rtol=RTOL, atol=1e-7):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------------
+# sample set bookkeeping
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("nrows,mean", [(0, 5), (1, 0), (257, 7), (1500, 33)])
+def test_bias_shift_bit_exact(ctx, oracle, nrows, mean):
+    raw = make_synth_csr(nrows, 97, mean, seed=11, binary=False)
+    tr = oracle.translate(raw)
+    dev = upload(ctx, raw, 97)
+    assert (dev.nrows, dev.nnz, dev.dim) == (tr.nrows, tr.nnz, 97)
+    assert dev.nnz == raw.nnz + raw.nrows
+    rowptr, col, val, label = dev.download()
+    np.testing.assert_array_equal(rowptr, tr.rowptr)
+    np.testing.assert_array_equal(col, tr.col)
+    np.testing.assert_array_equal(val, tr.val)
+    np.testing.assert_array_equal(label, tr.label)
+    dev.destroy()
+
+
+def test_upload_rejects_out_of_range_index(ctx):
+    from admm_amd import capi
+    with pytest.raises(capi.AdmmError):
+        ctx.csr_upload(np.array([0, 1], np.uint64), np.array([5], np.uint32), None,
+                       np.array([1], np.float32), dim=6, add_bias=True)  # 5+1 needs dim >= 7
+
+
+def test_wtest_known_answers_on_gpu(ctx, oracle):
+    with open(os.path.join(GOLDEN, "wtest_known_answers.json")) as f:
+        known = json.load(f)
+    raw = oracle.parse_libsvm(os.path.join(GOLDEN, "wtest.libsvm"))
+    prm = known["ftrl_params"]
+    dev = upload(ctx, raw, prm["dim"])
+    w, z, n, off, reg = (ctx.vec(prm["dim"]) for _ in range(5))
+    for expect in known["ftrl_passes"]:
+        dev.ftrl_pass(w, z, n, off, reg, prm["alpha"], prm["beta"], prm["l_1"], prm["l_2"])
+        hw, hz, hn = w.download(), z.download(), n.download()
+        for j in known["touched"]:
+            close(hw[j], expect["w"], atol=0)
+            close(hz[j], expect["z"], atol=0)
+            close(hn[j], expect["n"], atol=0)
+    ll, auc, n_rows = dev.metrics([off, reg], want_auc=False)
+    assert "%.7f" % ll == known["zero_weight_logloss"] and n_rows == 1
+    dev.destroy()
+
+
+# ------------------------------------------------------------------------------------------------
+# metrics
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("binary,label01,mean", [(True, True, 9), (False, False, 40), (True, True, 130)])
+def test_predict_logloss_auc(ctx, oracle, binary, label01, mean):
+    dim = 513
+    raw = make_synth_csr(3000, dim, mean, seed=21, binary=binary, label01=label01)
+    tr = oracle.translate(raw)
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 0.4, dim).astype(np.float32)
+    b = rng.normal(0, 0.05, dim).astype(np.float32)
+    dev = upload(ctx, raw, dim)
+    dx, db = ctx.vec(dim, x), ctx.vec(dim, b)
+    p = dev.predict([dx, db])
+    s64, p_ref = oracle.logloss_sum_f64(tr, [x, b], want_p=True)
+    close(p, p_ref, atol=1e-7)
+    ll, auc, n = dev.metrics([dx, db])
+    assert n == 3000
+    close(ll, s64 / 3000)
+    close(ll, oracle.logloss(tr, [x, b]), rtol=2e-5)      # the float running sum of the reference
+    close(auc, oracle.auc_from_scores(p_ref, tr.label, f64=True))
+    close(auc, oracle.auc(tr, [x, b]), rtol=5e-5)         # float ranks / float accumulators
+    dev.destroy()
+
+
+def test_auc_with_ties_and_zero_weights(ctx, oracle):
+    dim = 64
+    raw = make_synth_csr(800, dim, 3, seed=8)       # short rows: many identical scores
+    tr = oracle.translate(raw)
+    dev = upload(ctx, raw, dim)
+    zero = ctx.vec(dim)
+    ll, auc, _ = dev.metrics([zero])
+    assert "%.7f" % ll == "0.6931472"
+    assert auc == pytest.approx(0.5, abs=1e-12)
+    x = np.zeros(dim, np.float32)
+    x[1:6] = [0.5, -0.5, 0.25, 0.0, 1.0]
+    _, auc, _ = dev.metrics([ctx.vec(dim, x)])
+    close(auc, oracle.auc(tr, [x]))
+    dev.destroy()
+
+
+# ------------------------------------------------------------------------------------------------
+# FTRL
+# ------------------------------------------------------------------------------------------------
+
+def _ftrl_both(ctx, oracle, raw, dim, params, passes=1, batch=1, panel=0):
+    tr = oracle.translate(raw)
+    rng = np.random.default_rng(17)
+    reg = rng.normal(0, 0.02, dim).astype(np.float32)
+    off = rng.normal(0, 0.02, dim).astype(np.float32)
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    dev = upload(ctx, raw, dim)
+    if batch > 1:
+        dev.build_transposed(panel_rows=panel or batch, col_block=128)
+    w, z, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    doff, dreg = ctx.vec(dim, off), ctx.vec(dim, reg)
+    for _ in range(passes):
+        oracle.ftrl_run(tr, hw, hz, hn, off, reg, *params, batch=batch)
+        dev.ftrl_pass(w, z, n, doff, dreg, *params, batch=batch)
+    out = (w.download(), z.download(), n.download()), (hw, hz, hn)
+    dev.destroy()
+    return out
+
+
+@pytest.mark.parametrize("binary,label01,mean", [(True, True, 12), (False, False, 30), (True, True, 90)])
+def test_ftrl_sequential_pass(ctx, oracle, binary, label01, mean):
+    dim = 301
+    raw = make_synth_csr(2000, dim, mean, seed=31, binary=binary, label01=label01)
+    # hyper-parameters of script/start.sh:15-31
+    got, ref = _ftrl_both(ctx, oracle, raw, dim, (0.01, 1.0, 0.4, 2.5), passes=2)
+    for g, r in zip(got, ref):
+        close(g, r, atol=1e-6 * max(1.0, np.abs(r).max()))
+
+
+def test_ftrl_sequential_admm_constants(ctx, oracle):
+    dim = 200
+    raw = make_synth_csr(1500, dim, 20, seed=33)
+    got, ref = _ftrl_both(ctx, oracle, raw, dim, (0.1, 1.0, 1.0, 200.0))   # src/workers.cc:53-54
+    for g, r in zip(got, ref):
+        close(g, r, atol=1e-6)
+
+
+def test_ftrl_rows_with_repeated_columns(ctx, oracle):
+    from oracle import oracle as orc
+    rowptr = np.array([0, 3, 5, 8], np.uint64)
+    col = np.array([2, 2, 5, 1, 1, 0, 4, 0], np.uint32)
+    val = np.array([1, 2, 1, 1, 1, .5, 1, 1], np.float32)
+    raw = orc.Csr(rowptr, col, val, np.array([1, 0, 1], np.float32), 8)
+    got, ref = _ftrl_both(ctx, oracle, raw, 8, (0.05, 1.0, 0.01, 0.5), passes=3)
+    for g, r in zip(got, ref):
+        close(g, r, atol=1e-6)
+
+
+@pytest.mark.parametrize("batch", [64, 500])
+def test_ftrl_minibatch(ctx, oracle, batch):
+    dim = 301
+    raw = make_synth_csr(1700, dim, 25, seed=35)
+    got, ref = _ftrl_both(ctx, oracle, raw, dim, (0.05, 1.0, 0.2, 1.5), passes=2, batch=batch)
+    for g, r in zip(got, ref):
+        close(g, r, rtol=5e-5, atol=2e-6)    # float atomics order inside a batch
+
+
+# ------------------------------------------------------------------------------------------------
+# batch objective, L-BFGS
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("binary,mean,panel", [(True, 15, 0), (False, 60, 300)])
+def test_logistic_fg(ctx, oracle, binary, mean, panel):
+    dim = 700
+    raw = make_synth_csr(2500, dim, mean, seed=41, binary=binary)
+    tr = oracle.translate(raw)
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 0.3, dim).astype(np.float32)
+    z = rng.normal(0, 0.3, dim).astype(np.float32)
+    yd = rng.normal(0, 0.05, dim).astype(np.float32)
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, None, z, yd, 0.7)
+    dev = upload(ctx, raw, dim).build_transposed(panel_rows=panel, col_block=256)
+    g = ctx.vec(dim)
+    f = dev.logistic_fg(ctx.vec(dim, x), g, z=ctx.vec(dim, z), ydual=ctx.vec(dim, yd), rho=0.7)
+    close(f, f_ref)
+    close(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
+    # a second call must start from clean accumulators
+    f2 = dev.logistic_fg(ctx.vec(dim, x), g, z=ctx.vec(dim, z), ydual=ctx.vec(dim, yd), rho=0.7)
+    close(f2, f_ref)
+    close(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
+    dev.destroy()
+
+
+def test_lbfgs_solve(ctx, oracle):
+    dim = 120
+    raw = make_synth_csr(1500, dim, 10, seed=43)
+    tr = oracle.translate(raw)
+    z = np.zeros(dim, np.float32)
+
+    def fg(xx):
+        return oracle.logistic_fg(tr, dim, xx, None, z, None, 1.0)
+
+    x_ref, f_ref, _, _ = oracle.lbfgs_solve(np.zeros(dim, np.float32), fg, max_iter=80, epsilon=1e-6)
+    dev = upload(ctx, raw, dim).build_transposed(col_block=64)
+    x = ctx.vec(dim)
+    res = dev.lbfgs_solve(x, z=ctx.vec(dim), rho=1.0, max_iter=80, epsilon=1e-6)
+    close(res["f"], f_ref, rtol=1e-6)
+    close(x.download(), x_ref, rtol=1e-3, atol=2e-4)   # both converged to the same minimiser
+    # and one short run follows the same trajectory step for step
+    x_ref, f_ref, ev_ref, it_ref = oracle.lbfgs_solve(np.zeros(dim, np.float32), fg, max_iter=4)
+    x.zero()
+    res = dev.lbfgs_solve(x, z=ctx.vec(dim), rho=1.0, max_iter=4)
+    assert (res["evals"], res["iters"]) == (ev_ref, it_ref)
+    close(res["f"], f_ref)
+    close(x.download(), x_ref, rtol=1e-4, atol=1e-6)
+    dev.destroy()
+
+
+# ------------------------------------------------------------------------------------------------
+# consensus algebra
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("l1", [0.0, 0.3])
+def test_consensus_kernels(ctx, oracle, l1):
+    dim = 100003
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=dim).astype(np.float32)
+    y = rng.normal(size=dim).astype(np.float32)
+    zold = rng.normal(size=dim).astype(np.float32)
+    rho, gv = np.float32(0.01), np.float32(4.0)
+    dx, dy, dz, dp = ctx.vec(dim, x), ctx.vec(dim, y), ctx.vec(dim, zold), ctx.vec(dim)
+    ctx.payload(dx, dy, rho, dp)
+    p_ref = oracle.payload(x, y, rho)
+    np.testing.assert_array_equal(dp.download(), p_ref)
+    total = (p_ref * 3).astype(np.float32)
+    dt = ctx.vec(dim, total)
+    z_ref = oracle.global_update(total, 3, rho, gv, np.float32(l1))
+    # separate kernels
+    dz2, dy2 = ctx.vec(dim), ctx.vec(dim, y)
+    ctx.global_update(dt, 3, rho, gv, l1, dz2)
+    ctx.dual_update(dy2, dx, dz2, rho)
+    # fused kernel
+    r2, s2 = ctx.consensus(dt, 3, rho, gv, l1, dx, dy, dz)
+    y_ref = y.copy()
+    oracle.dual_update(y_ref, x, z_ref, rho)
+    r2_ref, s2_ref = oracle.residuals(x, z_ref, zold, rho)
+    for zz, yy in ((dz2, dy2), (dz, dy)):
+        close(zz.download(), z_ref, rtol=2e-7, atol=0)
+        close(yy.download(), y_ref, rtol=1e-6, atol=1e-7)
+    close(r2, r2_ref, rtol=1e-9)
+    close(s2, s2_ref, rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic generator
+# ------------------------------------------------------------------------------------------------
+
+def test_synth_generator_properties(ctx):
+    dim = 1 << 14
+    a = ctx.csr_synth(5000, dim, 40, seed=7)
+    rowptr, col, val, label = a.download()
+    assert rowptr[0] == 0 and rowptr[-1] == a.nnz == col.shape[0]
+    lens = np.diff(rowptr.astype(np.int64))
+    assert lens.min() >= 1 and 30 < lens.mean() < 45
+    assert (val == 1.0).all() and set(np.unique(label)) <= {0.0, 1.0}
+    assert 0.05 < label.mean() < 0.95
+    for r in range(0, 5000, 97):
+        row = col[rowptr[r]:rowptr[r + 1]].astype(np.int64)
+        assert row[0] == 0 and (np.diff(row) > 0).all() and row[-1] < dim
+    # power law: the most frequent feature is far more frequent than the median one
+    counts = np.bincount(col[col > 0], minlength=dim)
+    assert counts.max() > 50 * max(1, np.median(counts[counts > 0]))
+    # determinism and shard consistency: rows [2000, 3000) generated alone are identical
+    b = ctx.csr_synth(1000, dim, 40, seed=7, row_offset=2000)
+    rp2, col2, _, lab2 = b.download()
+    np.testing.assert_array_equal(col2, col[rowptr[2000]:rowptr[3000]])
+    np.testing.assert_array_equal(lab2, label[2000:3000])
+    a.destroy()
+    b.destroy()
+
+
+def test_sweeps_on_generated_set(ctx, oracle):
+    """the generated set (long rows, lanes-per-row 32) through both sweeps against the oracle"""
+    from oracle import oracle as orc
+    dim = 1 << 15
+    dev = ctx.csr_synth(20000, dim, 100, seed=3).build_transposed(panel_rows=6000)
+    tr = orc.Csr(*dev.download(), dim)
+    rng = np.random.default_rng(4)
+    x = rng.normal(0, 0.1, dim).astype(np.float32)
+    z = rng.normal(0, 0.1, dim).astype(np.float32)
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, None, z, None, 0.01)
+    g = ctx.vec(dim)
+    f = dev.logistic_fg(ctx.vec(dim, x), g, z=ctx.vec(dim, z), rho=0.01)
+    close(f, f_ref)
+    close(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
+    dev.destroy()
