@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
       if (WRITE && keep) {
         a.col[ob + 1 + before] = id + 1u;
         a.val[ob + 1 + before] = 1.0f;
-        margin += wstar_of(a.s.seed, id);
+        margin += wstar_of(a.s.model_seed, id);
       }
       __syncthreads();
       if (lane == 0) outn += (uint32_t)__popcll(m);

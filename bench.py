@@ -36,7 +36,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rows", type=int, default=100_000_000, help="total rows over all ranks")
     ap.add_argument("--dim", type=int, default=1 << 22)
-    ap.add_argument("--mean-nnz", type=float, default=99.0, help="raw features per row (bias adds 1)")
+    ap.add_argument("--mean-nnz", type=float, default=131.0,
+                    help="feature draws per row; ~99 stay after de-duplication at 2^22 features, +1 bias")
     ap.add_argument("--lbfgs-iters", type=int, default=3)
     ap.add_argument("--panel-rows", type=int, default=1 << 20)
     ap.add_argument("--col-block", type=int, default=16384)
@@ -212,7 +213,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "ADMM-LR L1+L2, synthetic %d rows x %d features, ~%d nnz/row, row-sharded over %d GPU(s)"
-                            % (rows_total, args.dim, round(args.mean_nnz) + 1, world),
+                            % (rows_total, args.dim, round(nnz_total / rows_total), world),
                 "local_solver": "lbfgs (max_iter %d)" % args.lbfgs_iters,
                 "rows_total": rows_total, "dim": args.dim, "nnz_total": nnz_total,
                 "objective_gradient_evals_total": evals_total,

@@ -86,9 +86,10 @@ int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint32_t *col, 
 typedef struct admm_synth_spec {
   uint64_t nrows;
   uint64_t dim;        /* including the bias column */
-  uint64_t seed;
+  uint64_t seed;       /* row contents */
+  uint64_t model_seed; /* hidden model w* behind the labels (share it between train and test sets) */
   uint64_t row_offset; /* global index of this shard's first row */
-  float mean_nnz;      /* mean raw features per row (before the bias entry) */
+  float mean_nnz;      /* mean feature draws per row; duplicates are dropped, the bias entry is added */
   float zipf_s;        /* > 1 */
   int len_dist;        /* 0: ~Poisson(mean_nnz); 1: log-normal heavy tail with the same mean */
   float tail_sigma;    /* log-normal sigma for len_dist 1 */
