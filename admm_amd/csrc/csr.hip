@@ -122,6 +122,27 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
   }
 }
 
+__global__ void __launch_bounds__(256) k_absmax(const float *__restrict__ v, uint64_t n, double *__restrict__ partials) {
+  __shared__ float sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  float m = 0.0f;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float a = fabsf(v[i]);
+    m = (a > m || a != a) ? a : m;  // NaN propagates
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_down(m, off, 64);
+    m = (o > m || o != o) ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = sh[0];
+    for (int i = 1; i < 4; ++i) r = (sh[i] > r || sh[i] != sh[i]) ? sh[i] : r;
+    partials[blockIdx.x] = (double)r;
+  }
+}
+
 // ---- synthetic generator ------------------------------------------------------------------------
 
 __device__ __host__ inline uint64_t mix64(uint64_t x) {
@@ -160,6 +181,7 @@ struct SynthArgs {
   int kbits;
   float zipf_a, zipf_top;  // a = 1 - s ; top = (nfeat+1)^a - 1
   float ln_mu;
+  int noscatter;  // development switch: keep ids equal to their frequency rank
   uint64_t *rowlen;        // pass 1 output (entries per row incl. bias)
   const uint64_t *rowptr;  // pass 2 input
   uint32_t *col;
@@ -196,7 +218,7 @@ __global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
         uint32_t rank = (uint32_t)x;
         rank = rank < 1 ? 0 : rank - 1;
         if (rank >= a.nfeat) rank = a.nfeat - 1;
-        id = scatter_id(rank, a.nfeat, a.kbits);
+        id = a.noscatter ? rank : scatter_id(rank, a.nfeat, a.kbits);
       }
       ids[k] = id;
     }
@@ -261,11 +283,11 @@ int ensure_rowbuf(admm_csr *csr) {
 int ensure_taccum(admm_csr *csr) {
   if (csr->d_g1) return ADMM_OK;
   const uint64_t padded = (uint64_t)csr->nblocks * csr->col_block;
-  ADMM_HIP_CHECK(hipMalloc(&csr->d_g1, sizeof(float) * padded));
-  ADMM_HIP_CHECK(hipMalloc(&csr->d_g2, sizeof(float) * padded));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_g1, sizeof(long long) * padded));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_g2, sizeof(long long) * padded));
   ADMM_HIP_CHECK(hipMalloc(&csr->d_mask, sizeof(uint32_t) * (padded / 32 + 1)));
-  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g1, 0, sizeof(float) * padded, csr->ctx->stream));
-  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g2, 0, sizeof(float) * padded, csr->ctx->stream));
+  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g1, 0, sizeof(long long) * padded, csr->ctx->stream));
+  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g2, 0, sizeof(long long) * padded, csr->ctx->stream));
   ADMM_HIP_CHECK(hipMemsetAsync(csr->d_mask, 0, sizeof(uint32_t) * (padded / 32 + 1), csr->ctx->stream));
   return ADMM_OK;
 }
@@ -346,8 +368,8 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
     }                                                                                      \
   } while (0)
   UP_CHECK(hipMalloc(&c->d_rowptr, sizeof(uint64_t) * (nrows + 1)));
-  UP_CHECK(hipMalloc(&c->d_col, sizeof(uint32_t) * std::max<uint64_t>(c->nnz, 1)));
-  if (keep_val) UP_CHECK(hipMalloc(&c->d_val, sizeof(float) * std::max<uint64_t>(c->nnz, 1)));
+  UP_CHECK(hipMalloc(&c->d_col, sizeof(uint32_t) * (c->nnz + 8)));
+  if (keep_val) UP_CHECK(hipMalloc(&c->d_val, sizeof(float) * (c->nnz + 8)));
   UP_CHECK(hipMalloc(&c->d_label, sizeof(float) * std::max<uint64_t>(nrows, 1)));
   if (nrows) UP_CHECK(hipMemcpyAsync(c->d_label, label, sizeof(float) * nrows, hipMemcpyHostToDevice, ctx->stream));
   if (!add_bias) {
@@ -432,9 +454,9 @@ extern "C" int admm_csr_destroy(admm_csr *csr) {
 extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block) {
   ADMM_REQUIRE(csr, "admm_csr_build_transposed: csr is NULL");
   admm_ctx *ctx = csr->ctx;
-  if (col_block == 0) col_block = 16384;
-  ADMM_REQUIRE(col_block <= 16384 && col_block >= 64 && (col_block % 64) == 0,
-               "admm_csr_build_transposed: col_block must be a multiple of 64 in [64, 16384]");
+  if (col_block == 0) col_block = 8192;
+  ADMM_REQUIRE(col_block <= 8192 && col_block >= 64 && (col_block % 64) == 0,
+               "admm_csr_build_transposed: col_block must be a multiple of 64 in [64, 8192]");
   if (panel_rows == 0) panel_rows = 1u << 20;
   ADMM_HIP_CHECK(hipSetDevice(ctx->device));
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -491,9 +513,9 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
     return ADMM_ERR_STATE;
   }
   ADMM_HIP_CHECK(hipMalloc(&csr->d_tptr, sizeof(uint64_t) * (ncells + 1)));
-  ADMM_HIP_CHECK(hipMalloc(&csr->d_trow, sizeof(uint32_t) * std::max<uint64_t>(run, 1)));
-  ADMM_HIP_CHECK(hipMalloc(&csr->d_tcol, sizeof(uint16_t) * std::max<uint64_t>(run, 1)));
-  if (csr->d_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_tval, sizeof(float) * std::max<uint64_t>(run, 1)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_trow, sizeof(uint32_t) * (run + 8)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_tcol, sizeof(uint16_t) * (run + 8)));
+  if (csr->d_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_tval, sizeof(float) * (run + 8)));
   ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_tptr, csr->h_tptr.data(), sizeof(uint64_t) * (ncells + 1), hipMemcpyHostToDevice, ctx->stream));
   // cursors start at the cell bases
   ADMM_HIP_CHECK(hipMemcpyAsync(d_cnt, csr->h_tptr.data(), sizeof(uint64_t) * (ncells + 1), hipMemcpyHostToDevice, ctx->stream));
@@ -507,6 +529,25 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   }
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   hipFree(d_cnt);
+  // fixed-point scale of the accumulators: |r * val| <= vmax for |r| <= 1, at most panel_rows
+  // addends per column and cell, everything below 2^61
+  csr->vmax = 1.0f;
+  if (csr->d_val && csr->nnz) {
+    const int g = grid_for(csr->nnz, 256, ctx->cu_count * 8);
+    hipLaunchKernelGGL(k_absmax, dim3(g), dim3(256), 0, ctx->stream, csr->d_val, csr->nnz, ctx->d_partials);
+    std::vector<double> hp(g);
+    ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), ctx->d_partials, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+    ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double m = 0;
+    for (double v : hp) m = std::max(m, v);
+    ADMM_REQUIRE(std::isfinite(m), "admm_csr_build_transposed: non-finite feature value");
+    csr->vmax = (float)std::max(1.0, m);
+  }
+  int need = 0;
+  while ((1ull << need) < panel_rows && need < 40) ++need;
+  int vbits = 0;
+  while (std::ldexp(1.0, vbits) < (double)csr->vmax) ++vbits;
+  csr->fx_shift = std::max(8, std::min(40, 61 - need - vbits));
   csr->has_t = true;
   ADMM_TRY(ensure_taccum(csr));
   return ADMM_OK;
@@ -532,6 +573,7 @@ extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_c
   a.zipf_a = 1.0f - spec->zipf_s;
   a.zipf_top = powf((float)a.nfeat + 1.0f, a.zipf_a) - 1.0f;
   a.ln_mu = logf(spec->mean_nnz) - 0.5f * spec->tail_sigma * spec->tail_sigma;
+  a.noscatter = getenv("ADMM_SYNTH_NOSCATTER") != nullptr;
   auto fail = [&](const char *what, hipError_t e) {
     set_error("admm_csr_synth: %s: %s", what, hipGetErrorString(e));
     free_csr(c);
@@ -566,8 +608,8 @@ extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_c
   hipFree(d_len);
   if (e != hipSuccess) return fail("length pass", e);
   c->nnz = total;
-  if ((e = hipMalloc(&c->d_col, sizeof(uint32_t) * std::max<uint64_t>(total, 1))) != hipSuccess) return fail("col", e);
-  if ((e = hipMalloc(&c->d_val, sizeof(float) * std::max<uint64_t>(total, 1))) != hipSuccess) return fail("val", e);
+  if ((e = hipMalloc(&c->d_col, sizeof(uint32_t) * (total + 8))) != hipSuccess) return fail("col", e);
+  if ((e = hipMalloc(&c->d_val, sizeof(float) * (total + 8))) != hipSuccess) return fail("val", e);
   a.rowptr = c->d_rowptr;
   a.col = c->d_col;
   a.val = c->d_val;

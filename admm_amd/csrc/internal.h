@@ -95,9 +95,12 @@ struct admm_csr {
   uint16_t *d_tcol = nullptr;
   float *d_tval = nullptr;  // nullptr when d_val is
   std::vector<uint64_t> h_tptr;
-  // per-coordinate accumulators for the transposed sweep (dim floats each) + touched bitmap
-  float *d_g1 = nullptr, *d_g2 = nullptr;
+  // per-coordinate accumulators of the transposed sweep: 64-bit fixed point (value * 2^fx_shift),
+  // so that sums are exact integer adds (order-independent, reproducible) + touched bitmap
+  long long *d_g1 = nullptr, *d_g2 = nullptr;
   uint32_t *d_mask = nullptr;
+  int fx_shift = 40;
+  float vmax = 1.0f;  // max |val| of the set
 };
 
 namespace admm_impl {

@@ -27,53 +27,78 @@ struct FwdArgs {
   float *out;
   double *partials;
   int mode;
+  int ablate;  // development switches, 0 in normal operation
 };
 
 __device__ inline float clamp35(float m) { return fmaxf(fminf(m, 35.0f), -35.0f); }
 
-// A wave owns a tile of 64 consecutive rows.  LPR lanes cooperate on one row (64/LPR rows at a
-// time); the 64 margins of the tile are parked in LDS so that the sigmoid / loss epilogue runs
-// once per tile with one row per lane and the per-row output is one coalesced 256-B store.
-template <int LPR>
+constexpr int kFwRows = 64;      // rows per workgroup tile
+constexpr int kFwChunk = 8192;   // stored entries staged per pass (32 KB of products in LDS)
+
+// CSR-stream forward sweep.  A workgroup owns 64 consecutive rows.  Their stored entries are one
+// contiguous range of col/val, which all 256 threads stream with 16-byte loads (four entries per
+// lane per load, many loads in flight), gather the weights, and park the products in LDS in
+// storage order.  Then four lanes per row add up that row's slice of LDS.  Rows longer than a
+// chunk simply span several passes.  The sigmoid / loss epilogue runs once per row.
 __global__ void __launch_bounds__(256) k_forward(FwdArgs a) {
-  __shared__ float sm[4][64];
+  __shared__ float prod[kFwChunk];
+  __shared__ unsigned long long rp[kFwRows + 1];
   __shared__ double shred[4];
-  constexpr int RPW = 64 / LPR;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane % LPR, grp = lane / LPR;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int trow = tid >> 2, q = tid & 3;
   const uint64_t nrows = a.r1 - a.r0;
-  const uint64_t ntiles = (nrows + 63) / 64;
+  const uint64_t ntiles = (nrows + kFwRows - 1) / kFwRows;
+  const float *__restrict__ w0 = a.w[0];
+  const float *__restrict__ w1 = a.nw > 1 ? a.w[1] : nullptr;
+  const float *__restrict__ w2 = a.nw > 2 ? a.w[2] : nullptr;
+  const float *__restrict__ w3 = a.nw > 3 ? a.w[3] : nullptr;
   double acc0 = 0, acc1 = 0;
-  // block-uniform trip count (the tile loop holds a workgroup barrier)
-  for (uint64_t tb = (uint64_t)blockIdx.x * 4; tb < ntiles; tb += (uint64_t)gridDim.x * 4) {
-    const uint64_t tile = tb + wave;
-    const uint64_t rbase = a.r0 + tile * 64;
-    const uint64_t myrow = rbase + lane;
-    const bool live = tile < ntiles && myrow < a.r1;
-    unsigned long long lo = 0, hi = 0;
-    if (live) {
-      lo = a.rowptr[myrow];
-      hi = a.rowptr[myrow + 1];
-    }
-    for (int i = 0; i < LPR; ++i) {
-      const int rit = i * RPW + grp;
-      const unsigned long long b = __shfl(lo, rit, 64), e = __shfl(hi, rit, 64);
-      float s = 0.0f;
-      for (unsigned long long k = b + sub; k < e; k += LPR) {
-        const uint32_t j = a.col[k];
-        float wj = a.w[0][j];
-        if (a.nw > 1) wj += a.w[1][j];
-        if (a.nw > 2) wj += a.w[2][j];
-        if (a.nw > 3) wj += a.w[3][j];
-        s += wj * (a.val ? a.val[k] : 1.0f);
-      }
-#pragma unroll
-      for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      if (sub == 0) sm[wave][rit] = s;
-    }
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t rbase = a.r0 + tile * kFwRows;
+    const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
+    if (tid <= nr) rp[tid] = a.rowptr[rbase + tid];
     __syncthreads();
-    if (live) {
-      const float m = sm[wave][lane];
+    const unsigned long long B = rp[0], E = rp[nr];
+    const unsigned long long myb = trow < nr ? rp[trow] : E, mye = trow < nr ? rp[trow + 1] : E;
+    float rowsum = 0.0f;
+    for (unsigned long long cb = B & ~3ull; cb < E; cb += kFwChunk) {
+#pragma unroll
+      for (int h = 0; h < kFwChunk / 1024; ++h) {
+        const unsigned long long k = cb + (unsigned long long)h * 1024 + (unsigned long long)tid * 4;
+        if (k < E) {
+          const uint4 c4 = *reinterpret_cast<const uint4 *>(a.col + k);
+          float4 v4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+          if (a.val) v4 = *reinterpret_cast<const float4 *>(a.val + k);
+          const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
+          const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+          float pr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = (k + e >= B) && (k + e < E);
+            const uint32_t j = ok ? cc[e] : 0u;
+            float wj = (a.ablate & 1) ? __int_as_float(0x3f800000u | (j & 0xFFu)) : w0[j];
+            if (w1) wj += w1[j];
+            if (w2) wj += w2[j];
+            if (w3) wj += w3[j];
+            pr[e] = ok ? wj * vv[e] : 0.0f;
+          }
+          *reinterpret_cast<float4 *>(prod + h * 1024 + tid * 4) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+        }
+      }
+      __syncthreads();
+      const unsigned long long s = myb > cb ? myb : cb;
+      const unsigned long long e = mye < cb + kFwChunk ? mye : cb + kFwChunk;
+      if (!(a.ablate & 2))
+        for (unsigned long long k = s + q; k < e; k += 4) rowsum += prod[k - cb];
+      else if (s < e) rowsum += prod[s - cb];
+      __syncthreads();
+    }
+    rowsum += __shfl_xor(rowsum, 1, 64);
+    rowsum += __shfl_xor(rowsum, 2, 64);
+    if (q == 0 && trow < nr) {
+      const uint64_t myrow = rbase + trow;
+      const float m = rowsum;
       const float lab = a.label[myrow];
       if (a.mode == FWD_EVAL) {
         // src/metrics.cc:104-105: double predict, -log p / -log(1-p)
@@ -97,20 +122,20 @@ __global__ void __launch_bounds__(256) k_forward(FwdArgs a) {
         acc1 += (double)(g * g);
       }
     }
-    __syncthreads();
+    __syncthreads();  // rp is rewritten by the next tile
   }
-  // block reduction of the two sums
   for (int off = 32; off > 0; off >>= 1) {
     acc0 += __shfl_down(acc0, off, 64);
     acc1 += __shfl_down(acc1, off, 64);
   }
+  __syncthreads();
   if (lane == 0) shred[wave] = acc0;
   __syncthreads();
-  if (threadIdx.x == 0) a.partials[0 * kMaxPartialBlocks + blockIdx.x] = shred[0] + shred[1] + shred[2] + shred[3];
+  if (tid == 0) a.partials[0 * kMaxPartialBlocks + blockIdx.x] = shred[0] + shred[1] + shred[2] + shred[3];
   __syncthreads();
   if (lane == 0) shred[wave] = acc1;
   __syncthreads();
-  if (threadIdx.x == 0) a.partials[1 * kMaxPartialBlocks + blockIdx.x] = shred[0] + shred[1] + shred[2] + shred[3];
+  if (tid == 0) a.partials[1 * kMaxPartialBlocks + blockIdx.x] = shred[0] + shred[1] + shred[2] + shred[3];
 }
 
 int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
@@ -130,17 +155,12 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.out = out_rows;
   a.partials = ctx->d_partials;
   a.mode = (int)mode;
-  const uint64_t ntiles = (r1 - r0 + 63) / 64;
-  const int grid = grid_for(ntiles * 64, 256, ctx->cu_count * 8);
+  if (const char *ab = getenv("ADMM_ABLATE")) a.ablate = atoi(ab) & 0xFF;
+  const uint64_t ntiles = (r1 - r0 + kFwRows - 1) / kFwRows;
+  const int grid = grid_for(ntiles * 256, 256, ctx->cu_count * 10);
   *nblocks_out = grid;
   KernelTimer t(ctx, ADMM_K_FORWARD);
-  switch (csr->fwd_lpr) {
-    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<4>), dim3(grid), dim3(256), 0, ctx->stream, a); break;
-    case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<8>), dim3(grid), dim3(256), 0, ctx->stream, a); break;
-    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<16>), dim3(grid), dim3(256), 0, ctx->stream, a); break;
-    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<32>), dim3(grid), dim3(256), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<64>), dim3(grid), dim3(256), 0, ctx->stream, a); break;
-  }
+  hipLaunchKernelGGL(k_forward, dim3(grid), dim3(256), 0, ctx->stream, a);
   ADMM_HIP_CHECK(hipGetLastError());
   return ADMM_OK;
 }
@@ -155,82 +175,137 @@ struct TArgs {
   const uint16_t *tcol;
   const float *tval;
   const float *rvec;  // one float per row
-  float *g1, *g2;
+  unsigned long long *g1, *g2;  // 64-bit fixed point, value * scale
   uint32_t *mask;
+  float scale;
   uint32_t nblocks, col_block;
-  uint64_t cell0;
+  uint64_t panel0, npanels;  // panels [panel0, panel0 + npanels) are swept by this launch
+  int ablate;                // development switches, 0 in normal operation
 };
 
 constexpr int kTThreads = 512;
 
-// One workgroup per (panel, column block) cell.  The cell's per-column sums are accumulated with
-// LDS atomics (the rows of a cell are visited almost in order, so the gather of rvec is close to
-// a sequential read), then added to the global per-column vector with one coalesced atomic pass.
+typedef unsigned long long fx_t;  // two's-complement fixed point held in an unsigned word
+
+__device__ inline fx_t to_fx(float x, float scale) { return (fx_t)(long long)(x * scale); }
+
+// Integer LDS atomics run three times as fast as float ones on gfx950 and make the sum
+// independent of the order of the adds.
+template <bool FTRL>
+__device__ inline void t_accumulate(fx_t *acc, fx_t *acc2, uint32_t *bits, uint32_t c, float x, float v, float scale) {
+  if (FTRL) {
+    atomicAdd(&acc[c], to_fx(x, scale));
+    atomicAdd(&acc2[c], to_fx(x * x, scale));
+    atomicOr(&bits[c >> 5], 1u << (c & 31));
+  } else {
+    atomicAdd(&acc[c], to_fx(x * v, scale));
+  }
+}
+
+// One workgroup per (panel, column block) cell.  The cell's entries are streamed with 16-byte
+// loads (four entries per lane per load); its per-column sums are accumulated with LDS atomics
+// while the per-row vector is gathered almost sequentially (a cell keeps its rows nearly in
+// order); the sums are then added to the global per-column vector in one coalesced atomic pass.
+// Workgroups whose index is equal modulo 8 share an XCD under round-robin dispatch; they are
+// given cells of the same panel so that the panel's slice of the per-row vector stays in that
+// XCD's L2 (placement affects speed only).
 template <bool FTRL>
 __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
-  extern __shared__ float acc[];  // [CB] (+ [CB] + [CB/32] bitmap in FTRL mode)
-  const uint64_t cell = a.cell0 + blockIdx.x;
+  extern __shared__ fx_t acc[];  // [CB] (+ [CB] + [CB/32] bitmap in FTRL mode)
+  const uint64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const uint64_t plocal = (slot / a.nblocks) * 8 + xcd;
+  if (plocal >= a.npanels) return;
+  const uint32_t blk = (uint32_t)(slot % a.nblocks);
+  const uint64_t cell = (a.panel0 + plocal) * a.nblocks + blk;
   const uint64_t beg = a.tptr[cell], end = a.tptr[cell + 1];
   if (beg == end) return;
   const uint32_t CB = a.col_block;
-  const uint32_t blk = (uint32_t)(cell % a.nblocks);
-  float *acc2 = acc + CB;
+  fx_t *acc2 = acc + CB;
   uint32_t *bits = reinterpret_cast<uint32_t *>(acc + 2 * CB);
+  const float scale = a.scale;
   for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
-    acc[c] = 0.0f;
-    if (FTRL) acc2[c] = 0.0f;
+    acc[c] = 0;
+    if (FTRL) acc2[c] = 0;
   }
   if (FTRL)
     for (uint32_t c = threadIdx.x; c < CB / 32; c += kTThreads) bits[c] = 0u;
   __syncthreads();
-  uint64_t k = beg + threadIdx.x;
-  // four independent entries per thread per trip keep more gathers in flight
-  for (; k + 3 * kTThreads < end; k += 4 * kTThreads) {
-    uint32_t r[4];
-    uint16_t c[4];
-    float v[4], x[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      r[u] = a.trow[k + u * kTThreads];
-      c[u] = a.tcol[k + u * kTThreads];
-      v[u] = (!FTRL && a.tval) ? a.tval[k + u * kTThreads] : 1.0f;
+  // head: up to 3 entries before the first 4-aligned index; tail: what is left after the body
+  const uint64_t body0 = (beg + 3) & ~3ull;
+  const uint64_t body1 = end & ~3ull;
+  if (body0 >= body1) {
+    for (uint64_t k = beg + threadIdx.x; k < end; k += kTThreads)
+      t_accumulate<FTRL>(acc, acc2, bits, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
+  } else {
+    if (threadIdx.x < body0 - beg) {
+      const uint64_t k = beg + threadIdx.x;
+      t_accumulate<FTRL>(acc, acc2, bits, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = a.rvec[r[u]];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (FTRL) {
-        atomicAdd(&acc[c[u]], x[u]);
-        atomicAdd(&acc2[c[u]], x[u] * x[u]);
-        atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31));
-      } else {
-        atomicAdd(&acc[c[u]], x[u] * v[u]);
+    if (threadIdx.x < end - body1) {
+      const uint64_t k = body1 + threadIdx.x;
+      t_accumulate<FTRL>(acc, acc2, bits, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
+    }
+    const bool use_val = !FTRL && a.tval != nullptr;
+    uint64_t k = body0 + (uint64_t)threadIdx.x * 4;
+    // two independent 4-entry groups per trip
+    for (; k + 4 * kTThreads < body1; k += 8 * kTThreads) {
+      const uint64_t k2 = k + 4 * kTThreads;
+      const uint4 ra = *reinterpret_cast<const uint4 *>(a.trow + k);
+      const uint4 rb = *reinterpret_cast<const uint4 *>(a.trow + k2);
+      const uint2 ca = *reinterpret_cast<const uint2 *>(a.tcol + k);
+      const uint2 cb = *reinterpret_cast<const uint2 *>(a.tcol + k2);
+      float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = va;
+      if (use_val) {
+        va = *reinterpret_cast<const float4 *>(a.tval + k);
+        vb = *reinterpret_cast<const float4 *>(a.tval + k2);
       }
+      float xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
+      if (a.ablate & 1) {
+        xa0 = __uint_as_float(ra.x), xa1 = __uint_as_float(ra.y), xa2 = __uint_as_float(ra.z), xa3 = __uint_as_float(ra.w);
+        xb0 = __uint_as_float(rb.x), xb1 = __uint_as_float(rb.y), xb2 = __uint_as_float(rb.z), xb3 = __uint_as_float(rb.w);
+      } else {
+        xa0 = a.rvec[ra.x], xa1 = a.rvec[ra.y], xa2 = a.rvec[ra.z], xa3 = a.rvec[ra.w];
+        xb0 = a.rvec[rb.x], xb1 = a.rvec[rb.y], xb2 = a.rvec[rb.z], xb3 = a.rvec[rb.w];
+      }
+      if (a.ablate & 2) {
+        const float sacc = xa0 * va.x + xa1 * va.y + xa2 * va.z + xa3 * va.w + xb0 * vb.x + xb1 * vb.y + xb2 * vb.z + xb3 * vb.w;
+        const uint32_t cs = (ca.x ^ ca.y ^ cb.x ^ cb.y) & 0xFFFu;
+        if (sacc == 123.456f) acc[cs] = 1;
+        continue;
+      }
+      t_accumulate<FTRL>(acc, acc2, bits, ca.x & 0xFFFFu, xa0, va.x, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, ca.x >> 16, xa1, va.y, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, ca.y & 0xFFFFu, xa2, va.z, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, ca.y >> 16, xa3, va.w, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, cb.x & 0xFFFFu, xb0, vb.x, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, cb.x >> 16, xb1, vb.y, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, cb.y & 0xFFFFu, xb2, vb.z, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, cb.y >> 16, xb3, vb.w, scale);
     }
-  }
-  for (; k < end; k += kTThreads) {
-    const uint32_t r = a.trow[k];
-    const uint16_t c = a.tcol[k];
-    const float x = a.rvec[r];
-    if (FTRL) {
-      atomicAdd(&acc[c], x);
-      atomicAdd(&acc2[c], x * x);
-      atomicOr(&bits[c >> 5], 1u << (c & 31));
-    } else {
-      atomicAdd(&acc[c], x * (a.tval ? a.tval[k] : 1.0f));
+    for (; k < body1; k += 4 * kTThreads) {
+      const uint4 ra = *reinterpret_cast<const uint4 *>(a.trow + k);
+      const uint2 ca = *reinterpret_cast<const uint2 *>(a.tcol + k);
+      float4 va = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (use_val) va = *reinterpret_cast<const float4 *>(a.tval + k);
+      const float xa0 = a.rvec[ra.x], xa1 = a.rvec[ra.y], xa2 = a.rvec[ra.z], xa3 = a.rvec[ra.w];
+      t_accumulate<FTRL>(acc, acc2, bits, ca.x & 0xFFFFu, xa0, va.x, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, ca.x >> 16, xa1, va.y, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, ca.y & 0xFFFFu, xa2, va.z, scale);
+      t_accumulate<FTRL>(acc, acc2, bits, ca.y >> 16, xa3, va.w, scale);
     }
   }
   __syncthreads();
+  if (a.ablate & 4) return;
   const uint64_t gbase = (uint64_t)blk * CB;
   for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
-    const float s = acc[c];
+    const fx_t s = acc[c];
     if (FTRL) {
       const uint32_t touched = (bits[c >> 5] >> (c & 31)) & 1u;
       if (touched) {
         atomicAdd(&a.g1[gbase + c], s);
         atomicAdd(&a.g2[gbase + c], acc2[c]);
       }
-    } else if (s != 0.0f) {
+    } else if (s != 0) {
       atomicAdd(&a.g1[gbase + c], s);
     }
   }
@@ -249,20 +324,35 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
   a.tcol = csr->d_tcol;
   a.tval = csr->d_tval;
   a.rvec = csr->d_rowbuf;
-  a.g1 = csr->d_g1;
-  a.g2 = csr->d_g2;
+  a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
+  a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
+  a.scale = std::ldexp(1.0f, csr->fx_shift);
   a.mask = csr->d_mask;
   a.nblocks = csr->nblocks;
   a.col_block = csr->col_block;
-  const uint64_t ncells = (p1 - p0) * csr->nblocks;
-  const size_t lds = ftrl_mode ? sizeof(float) * 2 * csr->col_block + sizeof(uint32_t) * (csr->col_block / 32)
-                               : sizeof(float) * csr->col_block;
+  if (const char *ab = getenv("ADMM_ABLATE")) a.ablate = (atoi(ab) >> 8) & 0xFF;
+  const size_t lds = ftrl_mode ? sizeof(fx_t) * 2 * csr->col_block + sizeof(uint32_t) * (csr->col_block / 32)
+                               : sizeof(fx_t) * csr->col_block;
+  if (lds > 64 * 1024) {
+    static bool raised[2] = {false, false};
+    if (!raised[ftrl_mode]) {
+      if (ftrl_mode)
+        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_transposed<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      else
+        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_transposed<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      raised[ftrl_mode] = true;
+    }
+  }
   KernelTimer t(ctx, ADMM_K_TRANSPOSED);
-  // the grid's x dimension is limited to 2^31-1 blocks; cut very long cell ranges
-  const uint64_t kMaxGrid = 1u << 30;
-  for (uint64_t c0 = 0; c0 < ncells; c0 += kMaxGrid) {
-    a.cell0 = p0 * csr->nblocks + c0;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(kMaxGrid, ncells - c0);
+  // keep each launch's grid below 2^30 workgroups
+  const uint64_t max_panels = std::max<uint64_t>(8, ((1ull << 30) / csr->nblocks) & ~7ull);
+  for (uint64_t q0 = p0; q0 < p1; q0 += max_panels) {
+    a.panel0 = q0;
+    a.npanels = std::min<uint64_t>(max_panels, p1 - q0);
+    const uint64_t groups = (a.npanels + 7) / 8;
+    const uint32_t grid = (uint32_t)(groups * 8 * csr->nblocks);
     if (ftrl_mode)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<true>), dim3(grid), dim3(kTThreads), lds, ctx->stream, a);
     else
@@ -278,7 +368,8 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
 
 // g = acc + y + rho (x - z), acc reset to 0; column 0 also receives the bias-column sum the
 // forward sweep produced (scalars[1]); partials row 2 <- y.(x-z) + rho/2 |x-z|^2
-__global__ void __launch_bounds__(256) k_fg_finish(float *__restrict__ accum, const float *__restrict__ x,
+__global__ void __launch_bounds__(256) k_fg_finish(long long *__restrict__ accum, double inv_scale,
+                                                   const float *__restrict__ x,
                                                    const float *__restrict__ z, const float *__restrict__ y,
                                                    float rho, const double *__restrict__ scalars, int add_bias,
                                                    float *__restrict__ g, uint64_t n, double *__restrict__ partials) {
@@ -286,9 +377,10 @@ __global__ void __launch_bounds__(256) k_fg_finish(float *__restrict__ accum, co
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   double reg = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    float a = accum[i];
-    accum[i] = 0.0f;
-    if (add_bias && i == 0) a += (float)scalars[1];
+    double ad = (double)accum[i] * inv_scale;
+    accum[i] = 0;
+    if (add_bias && i == 0) ad += scalars[1];
+    const float a = (float)ad;
     const float d = x[i] - (z ? z[i] : 0.0f);
     const float yd = y ? y[i] : 0.0f;
     g[i] = a + yd + rho * d;
@@ -340,8 +432,8 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
   const int grid = grid_for(csr->dim, 256, ctx->cu_count * 8);
   {
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
-    hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, x, z, ydual, rho,
-                       ctx->d_scalars, csr->has_bias ? 1 : 0, g_out, csr->dim, ctx->d_partials);
+    hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
+                       ydual, rho, ctx->d_scalars, csr->has_bias ? 1 : 0, g_out, csr->dim, ctx->d_partials);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
@@ -375,8 +467,8 @@ __global__ void __launch_bounds__(256) k_ftrl_wcur(const float *__restrict__ z, 
 
 // per coordinate touched in the batch: w <- wcur (lazy weight), n' = n + G2,
 // z += G1 - wcur (sqrt(n') - sqrt(n)) / alpha ; accumulators and bitmap are cleared
-__global__ void __launch_bounds__(256) k_ftrl_apply(float *__restrict__ g1, float *__restrict__ g2,
-                                                    uint32_t *__restrict__ mask, const float *__restrict__ wcur,
+__global__ void __launch_bounds__(256) k_ftrl_apply(long long *__restrict__ g1, long long *__restrict__ g2,
+                                                    double inv_scale, uint32_t *__restrict__ mask, const float *__restrict__ wcur,
                                                     float *__restrict__ w, float *__restrict__ z,
                                                     float *__restrict__ n, float alpha,
                                                     const double *__restrict__ scalars, int bias_rows,
@@ -384,7 +476,7 @@ __global__ void __launch_bounds__(256) k_ftrl_apply(float *__restrict__ g1, floa
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
     bool touched = (mask[i >> 5] >> (i & 31)) & 1u;
-    double G1 = g1[i], G2 = g2[i];
+    double G1 = (double)g1[i] * inv_scale, G2 = (double)g2[i] * inv_scale;
     if (bias_rows && i == 0) {
       touched = true;
       G1 += scalars[0];
@@ -398,8 +490,8 @@ __global__ void __launch_bounds__(256) k_ftrl_apply(float *__restrict__ g1, floa
       w[i] = wc;
       z[i] = (float)((double)z[i] + (G1 - sigma * (double)wc));
       n[i] = nnew;
-      g1[i] = 0.0f;
-      g2[i] = 0.0f;
+      g1[i] = 0;
+      g2[i] = 0;
     }
   }
 }
@@ -459,8 +551,8 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
     ADMM_TRY(launch_transposed(csr, true, p, p + 1));
     {
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
-      hipLaunchKernelGGL(k_ftrl_apply, dim3(egrid), dim3(256), 0, ctx->stream, csr->d_g1, csr->d_g2, csr->d_mask,
-                         wcur, w, z, n, alpha, ctx->d_scalars, csr->has_bias ? 1 : 0, csr->dim);
+      hipLaunchKernelGGL(k_ftrl_apply, dim3(egrid), dim3(256), 0, ctx->stream, csr->d_g1, csr->d_g2,
+                         std::ldexp(1.0, -csr->fx_shift), csr->d_mask, wcur, w, z, n, alpha, ctx->d_scalars, csr->has_bias ? 1 : 0, csr->dim);
       ADMM_HIP_CHECK(hipGetLastError());
       const uint64_t words = ((uint64_t)csr->nblocks * csr->col_block) / 32 + 1;
       hipLaunchKernelGGL(k_clear_mask, dim3(grid_for(words, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream,

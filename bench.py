@@ -40,7 +40,7 @@ def parse_args():
                     help="feature draws per row; ~99 stay after de-duplication at 2^22 features, +1 bias")
     ap.add_argument("--lbfgs-iters", type=int, default=3)
     ap.add_argument("--panel-rows", type=int, default=1 << 20)
-    ap.add_argument("--col-block", type=int, default=16384)
+    ap.add_argument("--col-block", type=int, default=8192)
     ap.add_argument("--test-frac", type=float, default=0.01)
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -102,7 +102,7 @@ int admm_csr_shape(const admm_csr *csr, uint64_t *nrows, uint64_t *nnz, uint64_t
 int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, float *val,
                       float *label);
 /* Build the column-block copy that the transposed sweep reads (X^T r, mini-batch FTRL):
- * rows are cut into panels of `panel_rows`, columns into blocks of `col_block` (<= 16384),
+ * rows are cut into panels of `panel_rows`, columns into blocks of `col_block` (<= 8192),
  * and each (panel, block) cell stores its entries contiguously.  0 picks defaults. */
 int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block);
 /* Bytes of HBM held by this sample set. */

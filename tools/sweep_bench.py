@@ -1,0 +1,40 @@
+"""Development aid: time the two sweeps of one objective/gradient evaluation on a synthetic set,
+optionally with ablation switches (ADMM_ABLATE: forward bits 0-7, transposed bits 8-15)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from admm_amd import capi  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=10_000_000)
+ap.add_argument("--dim", type=int, default=1 << 22)
+ap.add_argument("--draws", type=float, default=131)
+ap.add_argument("--panel-rows", type=int, default=1 << 20)
+ap.add_argument("--col-block", type=int, default=8192)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--ablate", type=str, default="0")
+args = ap.parse_args()
+
+ctx = capi.Context(0)
+s = ctx.csr_synth(args.rows, args.dim, args.draws, seed=1)
+s.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
+x, g = ctx.vec(args.dim), ctx.vec(args.dim)
+import numpy as np
+x.upload(np.random.default_rng(0).normal(0, 0.05, args.dim).astype(np.float32))
+rows, nnz = s.nrows, s.nnz
+fb = 8.0 * nnz + 16.0 * rows + 4.0 * args.dim
+tb = 8.0 * (nnz - rows) + 4.0 * rows + 4.0 * args.dim
+for ab in args.ablate.split(","):
+    os.environ["ADMM_ABLATE"] = ab
+    s.logistic_fg(x, g, rho=0.01)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(args.reps):
+        s.logistic_fg(x, g, rho=0.01)
+    f_ms, f_n = ctx.timing_get(capi.K_FORWARD)
+    t_ms, t_n = ctx.timing_get(capi.K_TRANSPOSED)
+    ctx.timing_enable(False)
+    print("ablate=%-6s rows=%d nnz=%d  forward %.3f ms (%.0f GB/s alg)  transposed %.3f ms (%.0f GB/s alg)"
+          % (ab, rows, nnz, f_ms / f_n, fb / (f_ms / f_n) / 1e6, t_ms / t_n, tb / (t_ms / t_n) / 1e6), flush=True)
