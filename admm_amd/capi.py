@@ -19,7 +19,7 @@ SYMBOLS = [
     "admm_vec_alloc", "admm_vec_free", "admm_vec_zero", "admm_vec_copy", "admm_vec_upload",
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
-    "admm_csr_build_transposed", "admm_csr_bytes", "admm_csr_destroy",
+    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_destroy",
     "admm_predict", "admm_metrics", "admm_ftrl_pass", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus",
     "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32",
@@ -81,6 +81,7 @@ def load():
         "admm_csr_shape": [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)],
         "admm_csr_download": [vp, vp, vp, vp, vp],
         "admm_csr_build_transposed": [vp, u64, C.c_uint32],
+        "admm_csr_relabel_by_frequency": [vp],
         "admm_csr_bytes": [vp, C.POINTER(u64), C.POINTER(u64)],
         "admm_csr_destroy": [vp],
         "admm_predict": [vp, C.POINTER(vp), i32, vp],
@@ -264,6 +265,10 @@ class SampleSet:
 
     def build_transposed(self, panel_rows=0, col_block=0):
         _check(self.ctx.L.admm_csr_build_transposed(self.h, int(panel_rows), int(col_block)))
+        return self
+
+    def relabel_by_frequency(self):
+        _check(self.ctx.L.admm_csr_relabel_by_frequency(self.h))
         return self
 
     def bytes(self):

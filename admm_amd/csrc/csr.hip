@@ -54,6 +54,7 @@ constexpr int kChunkRows = 512;
 struct TBuildArgs {
   const uint64_t *rowptr;
   const uint32_t *col;
+  const uint32_t *perm;  // relabelled sets: stored id -> original id (the copy keeps original ids)
   const float *val;
   uint64_t nrows, panel_rows;
   uint32_t col_block, nblocks;
@@ -85,7 +86,8 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
     __syncthreads();
     const uint64_t kb = a.rowptr[r0], ke = a.rowptr[r1];
     for (uint64_t k = kb + threadIdx.x; k < ke; k += 256) {
-      const uint32_t c = a.col[k];
+      uint32_t c = a.col[k];
+      if (a.perm) c = a.perm[c];
       if (a.skip_bias && c == 0) continue;
       atomicAdd(&cnt[c / a.col_block], 1u);
     }
@@ -107,7 +109,8 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
       for (uint64_t r = r0 + grp; r < r1; r += 16) {
         const uint64_t b = a.rowptr[r], e = a.rowptr[r + 1];
         for (uint64_t k = b + sub; k < e; k += 16) {
-          const uint32_t c = a.col[k];
+          uint32_t c = a.col[k];
+          if (a.perm) c = a.perm[c];
           if (a.skip_bias && c == 0) continue;
           const uint32_t blk = c / a.col_block;
           const uint32_t slot = atomicAdd(&cnt[blk], 1u);
@@ -274,6 +277,35 @@ __global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
   }
 }
 
+// ---- relabelling columns by frequency ------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_colcount(const uint64_t *__restrict__ rowptr,
+                                                  const uint32_t *__restrict__ col, uint64_t nrows,
+                                                  uint64_t chunk_stride, uint32_t *__restrict__ count) {
+  // chunks of 256 rows; only every chunk_stride-th chunk is counted (the ranking needs no more)
+  const uint64_t nchunks = (nrows + 255) / 256;
+  for (uint64_t ch = (uint64_t)blockIdx.x * chunk_stride; ch < nchunks; ch += (uint64_t)gridDim.x * chunk_stride) {
+    const uint64_t r0 = ch * 256, r1 = r0 + 256 < nrows ? r0 + 256 : nrows;
+    const uint64_t kb = rowptr[r0], ke = rowptr[r1];
+    for (uint64_t k = kb + threadIdx.x; k < ke; k += 256) atomicAdd(&count[col[k]], 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_iota(uint32_t *v, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) v[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_invert(const uint32_t *__restrict__ perm, uint32_t *__restrict__ inv, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) inv[perm[i]] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_relabel(uint32_t *__restrict__ col, const uint32_t *__restrict__ inv, uint64_t nnz) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += stride) col[i] = inv[col[i]];
+}
+
 int ensure_rowbuf(admm_csr *csr) {
   if (csr->d_rowbuf || csr->nrows == 0) return ADMM_OK;
   ADMM_HIP_CHECK(hipMalloc(&csr->d_rowbuf, sizeof(float) * csr->nrows));
@@ -306,7 +338,8 @@ static void free_csr(admm_csr *c) {
     hipStreamSynchronize(c->ctx->stream);
   }
   void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_tptr,
-                  c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask};
+                  c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask,
+                  c->d_wsum,   c->d_perm, c->d_inv};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;
@@ -434,7 +467,14 @@ extern "C" int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t
   admm_ctx *ctx = csr->ctx;
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (rowptr) ADMM_HIP_CHECK(hipMemcpy(rowptr, csr->d_rowptr, sizeof(uint64_t) * (csr->nrows + 1), hipMemcpyDeviceToHost));
-  if (col && csr->nnz) ADMM_HIP_CHECK(hipMemcpy(col, csr->d_col, sizeof(uint32_t) * csr->nnz, hipMemcpyDeviceToHost));
+  if (col && csr->nnz) {
+    ADMM_HIP_CHECK(hipMemcpy(col, csr->d_col, sizeof(uint32_t) * csr->nnz, hipMemcpyDeviceToHost));
+    if (csr->d_perm) {  // stored ids are frequency ranks: hand back the original ids
+      std::vector<uint32_t> perm(csr->dim);
+      ADMM_HIP_CHECK(hipMemcpy(perm.data(), csr->d_perm, sizeof(uint32_t) * csr->dim, hipMemcpyDeviceToHost));
+      for (uint64_t i = 0; i < csr->nnz; ++i) col[i] = perm[col[i]];
+    }
+  }
   if (val && csr->nnz) {
     if (csr->d_val) {
       ADMM_HIP_CHECK(hipMemcpy(val, csr->d_val, sizeof(float) * csr->nnz, hipMemcpyDeviceToHost));
@@ -443,6 +483,58 @@ extern "C" int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t
     }
   }
   if (label && csr->nrows) ADMM_HIP_CHECK(hipMemcpy(label, csr->d_label, sizeof(float) * csr->nrows, hipMemcpyDeviceToHost));
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
+  ADMM_REQUIRE(csr, "admm_csr_relabel_by_frequency: csr is NULL");
+  if (csr->d_perm || csr->nnz == 0) return ADMM_OK;
+  admm_ctx *ctx = csr->ctx;
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  const uint64_t dim = csr->dim;
+  uint32_t *count = nullptr, *count_sorted = nullptr, *ids = nullptr;
+  void *tmp = nullptr;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)count, (void *)count_sorted, (void *)ids, tmp})
+      if (p) hipFree(p);
+  };
+#define RL_CHECK(expr)                                                               \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      set_error("admm_csr_relabel_by_frequency: %s: %s", #expr, hipGetErrorString(e_)); \
+      cleanup();                                                                     \
+      return e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;              \
+    }                                                                                \
+  } while (0)
+  RL_CHECK(hipMalloc(&count, sizeof(uint32_t) * dim));
+  RL_CHECK(hipMalloc(&count_sorted, sizeof(uint32_t) * dim));
+  RL_CHECK(hipMalloc(&ids, sizeof(uint32_t) * dim));
+  RL_CHECK(hipMalloc(&csr->d_perm, sizeof(uint32_t) * dim));
+  RL_CHECK(hipMalloc(&csr->d_inv, sizeof(uint32_t) * dim));
+  RL_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t) * dim, ctx->stream));
+  const uint64_t stride = std::max<uint64_t>(1, csr->nnz / 400000000ull);
+  const int egrid = grid_for(dim, 256, ctx->cu_count * 8);
+  hipLaunchKernelGGL(k_colcount, dim3(ctx->cu_count * 8), dim3(256), 0, ctx->stream, csr->d_rowptr, csr->d_col,
+                     csr->nrows, stride, count);
+  if (csr->has_bias) {  // the bias column keeps id 0
+    const uint32_t top = 0xFFFFFFFFu;
+    RL_CHECK(hipMemcpyAsync(count, &top, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  hipLaunchKernelGGL(k_iota, dim3(egrid), dim3(256), 0, ctx->stream, ids, dim);
+  size_t bytes = 0;
+  RL_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, count, count_sorted, ids, csr->d_perm,
+                                                        (int64_t)dim, 0, 32, ctx->stream));
+  RL_CHECK(hipMalloc(&tmp, std::max<size_t>(bytes, 16)));
+  RL_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(tmp, bytes, count, count_sorted, ids, csr->d_perm,
+                                                        (int64_t)dim, 0, 32, ctx->stream));
+  hipLaunchKernelGGL(k_invert, dim3(egrid), dim3(256), 0, ctx->stream, csr->d_perm, csr->d_inv, dim);
+  hipLaunchKernelGGL(k_relabel, dim3(grid_for(csr->nnz, 256, ctx->cu_count * 16)), dim3(256), 0, ctx->stream,
+                     csr->d_col, csr->d_inv, csr->nnz);
+  RL_CHECK(hipGetLastError());
+  RL_CHECK(hipStreamSynchronize(ctx->stream));
+#undef RL_CHECK
+  cleanup();
   return ADMM_OK;
 }
 
@@ -457,7 +549,16 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   if (col_block == 0) col_block = 8192;
   ADMM_REQUIRE(col_block <= 8192 && col_block >= 64 && (col_block % 64) == 0,
                "admm_csr_build_transposed: col_block must be a multiple of 64 in [64, 8192]");
-  if (panel_rows == 0) panel_rows = 1u << 20;
+  if (panel_rows == 0) {
+    // about a million rows per panel, and a multiple of 8 panels when the set is large enough:
+    // the sweep hands each of the 8 XCDs its own panels
+    panel_rows = 1u << 20;
+    if (csr->nrows > (1u << 20)) {
+      uint64_t groups = 1;
+      while ((csr->nrows + 8 * groups - 1) / (8 * groups) > (1u << 20)) ++groups;
+      panel_rows = (csr->nrows + 8 * groups - 1) / (8 * groups);
+    }
+  }
   ADMM_HIP_CHECK(hipSetDevice(ctx->device));
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   // drop a previous copy
@@ -480,6 +581,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   TBuildArgs a{};
   a.rowptr = csr->d_rowptr;
   a.col = csr->d_col;
+  a.perm = csr->d_perm;
   a.val = csr->d_val;
   a.nrows = csr->nrows;
   a.panel_rows = panel_rows;

@@ -11,6 +11,7 @@ namespace admm_impl {
 struct SeqArgs {
   const uint64_t *rowptr;
   const uint32_t *col;
+  const uint32_t *perm;  // relabelled sets: stored id -> original id, else nullptr
   const float *val;
   const float *label;
   uint64_t nrows;
@@ -56,13 +57,13 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
     if (SERIAL) {
       if (lane == 0) {
         for (uint32_t k = 0; k < len; ++k) {
-          const uint32_t j = a.col[b + k];
+          const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
           w[j] = seq_weight(z[j], n[j], a.reg[j], a.alpha, a.beta, a.l1, a.l2);
         }
         if (!tail) {
           float sw = 0.0f, so = 0.0f;
           for (uint32_t k = 0; k < len; ++k) {
-            const uint32_t j = a.col[b + k];
+            const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
             const float v = a.val ? a.val[b + k] : 1.0f;
             sw += w[j] * v;
             so += a.offset[j] * v;
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
           const int y = a.label[row] > 0 ? 1 : 0;
           const float g = p - y;
           for (uint32_t k = 0; k < len; ++k) {
-            const uint32_t j = a.col[b + k];
+            const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
             const double sigma = (sqrt((double)(n[j] + g * g)) - sqrt((double)n[j])) / (double)a.alpha;
             z[j] = (float)((double)z[j] + ((double)g - sigma * (double)w[j]));
             n[j] = n[j] + g * g;
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
       for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t k = base + lane;
         if (k < len) {
-          const uint32_t j = a.col[b + k];
+          const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
           const float v = a.val ? a.val[b + k] : 1.0f;
           const float zj = z[j], nj = n[j];
           const float wj = seq_weight(zj, nj, a.reg[j], a.alpha, a.beta, a.l1, a.l2);
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
               nj = n0;
               wj = w0;
             } else {
-              j = a.col[b + k];
+              j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
               zj = z[j];
               nj = n[j];
               wj = w[j];
@@ -142,6 +143,7 @@ int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const floa
   SeqArgs a{};
   a.rowptr = csr->d_rowptr;
   a.col = csr->d_col;
+  a.perm = csr->d_perm;
   a.val = csr->d_val;
   a.label = csr->d_label;
   a.nrows = csr->nrows;

@@ -84,6 +84,9 @@ struct admm_csr {
   float *d_val = nullptr;  // nullptr = implicit 1
   float *d_label = nullptr;
   float *d_rowbuf = nullptr;  // nrows floats: p / residual / per-row gradient scale
+  float *d_wsum = nullptr;    // dim floats: the vector the forward sweep gathers (relabelled order)
+  // columns relabelled by decreasing frequency: d_col holds NEW ids; perm: new -> old, inv: old -> new
+  uint32_t *d_perm = nullptr, *d_inv = nullptr;
   uint32_t fwd_lpr = 16;      // lanes per row of the forward sweep
   // transposed (column-block) copy
   bool has_t = false;

@@ -28,48 +28,69 @@ struct FwdArgs {
   double *partials;
   int mode;
   int ablate;  // development switches, 0 in normal operation
+  uint32_t nhot;  // leading entries of w[0] cached in LDS
 };
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline float clamp35(float m) { return fmaxf(fminf(m, 35.0f), -35.0f); }
 
-constexpr int kFwRows = 64;      // rows per workgroup tile
-constexpr int kFwChunk = 8192;   // stored entries staged per pass (32 KB of products in LDS)
+// Forward sweep geometry: one workgroup of kFwThreads threads owns kFwRows consecutive rows;
+// kFwChunk stored entries are staged per pass; the first kFwHot entries of the gathered vector
+// are cached in LDS.
+constexpr int kFwThreads = 1024;
+constexpr int kFwRows = 256;
+constexpr int kFwChunk = 16384;
+constexpr int kFwHot = 16384;
+constexpr int kFwLanesPerRow = kFwThreads / kFwRows;  // 4
+constexpr size_t kFwLds = sizeof(float) * (kFwChunk + kFwHot) + sizeof(unsigned long long) * (kFwRows + 2) + 64;
 
-// CSR-stream forward sweep.  A workgroup owns 64 consecutive rows.  Their stored entries are one
-// contiguous range of col/val, which all 256 threads stream with 16-byte loads (four entries per
-// lane per load, many loads in flight), gather the weights, and park the products in LDS in
-// storage order.  Then four lanes per row add up that row's slice of LDS.  Rows longer than a
-// chunk simply span several passes.  The sigmoid / loss epilogue runs once per row.
-__global__ void __launch_bounds__(256) k_forward(FwdArgs a) {
-  __shared__ float prod[kFwChunk];
-  __shared__ unsigned long long rp[kFwRows + 1];
-  __shared__ double shred[4];
+// CSR-stream forward sweep.  The stored entries of a tile's rows are one contiguous range of
+// col/val, which all threads stream with 16-byte loads (four entries per lane per load, several
+// loads in flight), gather the weight of each entry, and park the products in LDS in storage
+// order.  Then four lanes per row add up that row's slice of LDS.  Rows longer than a chunk span
+// several passes.  The sigmoid / loss epilogue runs once per row.
+//
+// The gather is what bounds this kernel: a wave-wide gather of 64 scattered floats costs the
+// vector memory pipe about one clock per lane.  The sample set's columns are therefore relabelled
+// by decreasing frequency (power-law data: a few thousand columns hold most entries), the
+// gathered vector `wsum` is stored in that order, and its first kFwHot entries are kept in LDS,
+// where a gather is an order of magnitude cheaper.
+__global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
+  extern __shared__ unsigned long long fw_lds[];
+  unsigned long long *rp = fw_lds;                                      // [kFwRows + 1]
+  float *prod = reinterpret_cast<float *>(fw_lds + kFwRows + 2);        // [kFwChunk]
+  float *hot = prod + kFwChunk;                                         // [kFwHot]
+  __shared__ double shred[kFwThreads / 64];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int trow = tid >> 2, q = tid & 3;
+  const int trow = tid / kFwLanesPerRow, q = tid % kFwLanesPerRow;
   const uint64_t nrows = a.r1 - a.r0;
   const uint64_t ntiles = (nrows + kFwRows - 1) / kFwRows;
-  const float *__restrict__ w0 = a.w[0];
-  const float *__restrict__ w1 = a.nw > 1 ? a.w[1] : nullptr;
-  const float *__restrict__ w2 = a.nw > 2 ? a.w[2] : nullptr;
-  const float *__restrict__ w3 = a.nw > 3 ? a.w[3] : nullptr;
+  const float *__restrict__ wsum = a.w[0];
+  const uint32_t nhot = a.nhot;
+  for (uint32_t j = tid; j < nhot; j += kFwThreads) hot[j] = wsum[j];
   double acc0 = 0, acc1 = 0;
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint64_t rbase = a.r0 + tile * kFwRows;
     const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
     if (tid <= nr) rp[tid] = a.rowptr[rbase + tid];
-    __syncthreads();
+    __syncthreads();  // also orders the fill of hot[] before its first use
     const unsigned long long B = rp[0], E = rp[nr];
     const unsigned long long myb = trow < nr ? rp[trow] : E, mye = trow < nr ? rp[trow + 1] : E;
     float rowsum = 0.0f;
     for (unsigned long long cb = B & ~3ull; cb < E; cb += kFwChunk) {
 #pragma unroll
-      for (int h = 0; h < kFwChunk / 1024; ++h) {
-        const unsigned long long k = cb + (unsigned long long)h * 1024 + (unsigned long long)tid * 4;
+      for (int h = 0; h < kFwChunk / (4 * kFwThreads); ++h) {
+        const unsigned long long k = cb + (unsigned long long)h * (4 * kFwThreads) + (unsigned long long)tid * 4;
         if (k < E) {
-          const uint4 c4 = *reinterpret_cast<const uint4 *>(a.col + k);
-          float4 v4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-          if (a.val) v4 = *reinterpret_cast<const float4 *>(a.val + k);
+          // the matrix is read once per sweep: non-temporal loads keep it from evicting the
+          // gathered vector from L2
+          const u32x4 c4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.col + k));
+          f32x4 v4 = {1.0f, 1.0f, 1.0f, 1.0f};
+          if (a.val) v4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.val + k));
           const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
           const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
           float pr[4];
@@ -77,25 +98,25 @@ __global__ void __launch_bounds__(256) k_forward(FwdArgs a) {
           for (int e = 0; e < 4; ++e) {
             const bool ok = (k + e >= B) && (k + e < E);
             const uint32_t j = ok ? cc[e] : 0u;
-            float wj = (a.ablate & 1) ? __int_as_float(0x3f800000u | (j & 0xFFu)) : w0[j];
-            if (w1) wj += w1[j];
-            if (w2) wj += w2[j];
-            if (w3) wj += w3[j];
+            float wj;
+            if (a.ablate & 1) wj = __int_as_float(0x3f800000u | (j & 0xFFu));
+            else if (j < nhot) wj = hot[j];
+            else wj = wsum[j];
             pr[e] = ok ? wj * vv[e] : 0.0f;
           }
-          *reinterpret_cast<float4 *>(prod + h * 1024 + tid * 4) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+          *reinterpret_cast<float4 *>(prod + h * (4 * kFwThreads) + tid * 4) = make_float4(pr[0], pr[1], pr[2], pr[3]);
         }
       }
       __syncthreads();
       const unsigned long long s = myb > cb ? myb : cb;
       const unsigned long long e = mye < cb + kFwChunk ? mye : cb + kFwChunk;
       if (!(a.ablate & 2))
-        for (unsigned long long k = s + q; k < e; k += 4) rowsum += prod[k - cb];
+        for (unsigned long long k = s + q; k < e; k += kFwLanesPerRow) rowsum += prod[k - cb];
       else if (s < e) rowsum += prod[s - cb];
       __syncthreads();
     }
-    rowsum += __shfl_xor(rowsum, 1, 64);
-    rowsum += __shfl_xor(rowsum, 2, 64);
+#pragma unroll
+    for (int off = 1; off < kFwLanesPerRow; off <<= 1) rowsum += __shfl_xor(rowsum, off, 64);
     if (q == 0 && trow < nr) {
       const uint64_t myrow = rbase + trow;
       const float m = rowsum;
@@ -131,11 +152,35 @@ __global__ void __launch_bounds__(256) k_forward(FwdArgs a) {
   __syncthreads();
   if (lane == 0) shred[wave] = acc0;
   __syncthreads();
-  if (tid == 0) a.partials[0 * kMaxPartialBlocks + blockIdx.x] = shred[0] + shred[1] + shred[2] + shred[3];
+  if (tid == 0) {
+    double t = 0;
+    for (int i = 0; i < kFwThreads / 64; ++i) t += shred[i];
+    a.partials[0 * kMaxPartialBlocks + blockIdx.x] = t;
+  }
   __syncthreads();
   if (lane == 0) shred[wave] = acc1;
   __syncthreads();
-  if (tid == 0) a.partials[1 * kMaxPartialBlocks + blockIdx.x] = shred[0] + shred[1] + shred[2] + shred[3];
+  if (tid == 0) {
+    double t = 0;
+    for (int i = 0; i < kFwThreads / 64; ++i) t += shred[i];
+    a.partials[1 * kMaxPartialBlocks + blockIdx.x] = t;
+  }
+}
+
+// wsum[j] = sum over the weight vectors of w_g[perm[j]]  (perm == nullptr: identity)
+__global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, const float *__restrict__ w1,
+                                              const float *__restrict__ w2, const float *__restrict__ w3,
+                                              const uint32_t *__restrict__ perm, float *__restrict__ wsum,
+                                              uint64_t dim) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < dim; j += stride) {
+    const uint64_t o = perm ? perm[j] : j;
+    float s = w0[o];
+    if (w1) s += w1[o];
+    if (w2) s += w2[o];
+    if (w3) s += w3[o];
+    wsum[j] = s;
+  }
 }
 
 int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
@@ -143,6 +188,14 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(nw >= 1 && nw <= 4, "forward sweep: 1..4 weight vectors, got %d", nw);
   ADMM_REQUIRE(r0 <= r1 && r1 <= csr->nrows, "forward sweep: bad row range");
+  if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
+  {
+    KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_wsum, dim3(grid_for(csr->dim, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, w[0],
+                       nw > 1 ? w[1] : nullptr, nw > 2 ? w[2] : nullptr, nw > 3 ? w[3] : nullptr, csr->d_perm,
+                       csr->d_wsum, csr->dim);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
   FwdArgs a{};
   a.rowptr = csr->d_rowptr;
   a.col = csr->d_col;
@@ -150,17 +203,24 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.label = csr->d_label;
   a.r0 = r0;
   a.r1 = r1;
-  for (int i = 0; i < nw; ++i) a.w[i] = w[i];
-  a.nw = nw;
+  a.w[0] = csr->d_wsum;
+  a.nw = 1;
   a.out = out_rows;
   a.partials = ctx->d_partials;
   a.mode = (int)mode;
+  a.nhot = (uint32_t)std::min<uint64_t>(kFwHot, csr->dim);
   if (const char *ab = getenv("ADMM_ABLATE")) a.ablate = atoi(ab) & 0xFF;
+  static bool raised = false;
+  if (!raised) {
+    ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_forward),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds));
+    raised = true;
+  }
   const uint64_t ntiles = (r1 - r0 + kFwRows - 1) / kFwRows;
-  const int grid = grid_for(ntiles * 256, 256, ctx->cu_count * 10);
+  const int grid = grid_for(ntiles * kFwThreads, kFwThreads, ctx->cu_count);
   *nblocks_out = grid;
   KernelTimer t(ctx, ADMM_K_FORWARD);
-  hipLaunchKernelGGL(k_forward, dim3(grid), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_forward, dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
   ADMM_HIP_CHECK(hipGetLastError());
   return ADMM_OK;
 }
@@ -250,14 +310,14 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
     // two independent 4-entry groups per trip
     for (; k + 4 * kTThreads < body1; k += 8 * kTThreads) {
       const uint64_t k2 = k + 4 * kTThreads;
-      const uint4 ra = *reinterpret_cast<const uint4 *>(a.trow + k);
-      const uint4 rb = *reinterpret_cast<const uint4 *>(a.trow + k2);
-      const uint2 ca = *reinterpret_cast<const uint2 *>(a.tcol + k);
-      const uint2 cb = *reinterpret_cast<const uint2 *>(a.tcol + k2);
-      float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = va;
+      const u32x4 ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.trow + k));
+      const u32x4 rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.trow + k2));
+      const u32x2 ca = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.tcol + k));
+      const u32x2 cb = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.tcol + k2));
+      f32x4 va = {1.f, 1.f, 1.f, 1.f}, vb = va;
       if (use_val) {
-        va = *reinterpret_cast<const float4 *>(a.tval + k);
-        vb = *reinterpret_cast<const float4 *>(a.tval + k2);
+        va = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.tval + k));
+        vb = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.tval + k2));
       }
       float xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
       if (a.ablate & 1) {
@@ -283,10 +343,10 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
       t_accumulate<FTRL>(acc, acc2, bits, cb.y >> 16, xb3, vb.w, scale);
     }
     for (; k < body1; k += 4 * kTThreads) {
-      const uint4 ra = *reinterpret_cast<const uint4 *>(a.trow + k);
-      const uint2 ca = *reinterpret_cast<const uint2 *>(a.tcol + k);
-      float4 va = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (use_val) va = *reinterpret_cast<const float4 *>(a.tval + k);
+      const u32x4 ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.trow + k));
+      const u32x2 ca = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.tcol + k));
+      f32x4 va = {1.f, 1.f, 1.f, 1.f};
+      if (use_val) va = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.tval + k));
       const float xa0 = a.rvec[ra.x], xa1 = a.rvec[ra.y], xa2 = a.rvec[ra.z], xa3 = a.rvec[ra.w];
       t_accumulate<FTRL>(acc, acc2, bits, ca.x & 0xFFFFu, xa0, va.x, scale);
       t_accumulate<FTRL>(acc, acc2, bits, ca.x >> 16, xa1, va.y, scale);
@@ -504,13 +564,14 @@ __global__ void __launch_bounds__(256) k_clear_mask(uint32_t *mask, uint64_t wor
 // the trailing Predict of FtrlSolver::Run on the last row (src/ftrl.cc:140-141): refresh the
 // lazy weights of its coordinates
 __global__ void __launch_bounds__(64) k_ftrl_last_row(const uint64_t *__restrict__ rowptr,
-                                                      const uint32_t *__restrict__ col, uint64_t last,
+                                                      const uint32_t *__restrict__ col,
+                                                      const uint32_t *__restrict__ perm, uint64_t last,
                                                       const float *__restrict__ z, const float *__restrict__ n,
                                                       const float *__restrict__ c, float alpha, float beta,
                                                       float l1, float l2, float *__restrict__ w) {
   const uint64_t b = rowptr[last], e = rowptr[last + 1];
   for (uint64_t k = b + threadIdx.x; k < e; k += 64) {
-    const uint32_t j = col[k];
+    const uint32_t j = perm ? perm[col[k]] : col[k];
     w[j] = ftrl_weight(z[j], n[j], c[j], alpha, beta, l1, l2);
   }
 }
@@ -562,7 +623,7 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
   }
   if (csr->nrows) {
     hipLaunchKernelGGL(k_ftrl_last_row, dim3(1), dim3(64), 0, ctx->stream, csr->d_rowptr, csr->d_col,
-                       csr->nrows - 1, z, n, reg_offset, alpha, beta, l1, l2, w);
+                       csr->d_perm, csr->nrows - 1, z, n, reg_offset, alpha, beta, l1, l2, w);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   return ADMM_OK;

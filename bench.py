@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--mean-nnz", type=float, default=131.0,
                     help="feature draws per row; ~99 stay after de-duplication at 2^22 features, +1 bias")
     ap.add_argument("--lbfgs-iters", type=int, default=3)
-    ap.add_argument("--panel-rows", type=int, default=1 << 20)
+    ap.add_argument("--panel-rows", type=int, default=0)
     ap.add_argument("--col-block", type=int, default=8192)
     ap.add_argument("--test-frac", type=float, default=0.01)
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
@@ -110,8 +110,10 @@ def main():
     t_gen = time.perf_counter()
     train = ctx.csr_synth(r1 - r0, args.dim, args.mean_nnz, seed=args.seed, row_offset=r0)
     train.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
+    train.relabel_by_frequency()
     n_test = max(1, int((r1 - r0) * args.test_frac))
     test = ctx.csr_synth(n_test, args.dim, args.mean_nnz, seed=args.seed + 1, row_offset=r0)
+    test.relabel_by_frequency()
     ctx.sync()
     t_gen = time.perf_counter() - t_gen
 

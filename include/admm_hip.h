@@ -105,6 +105,12 @@ int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, floa
  * rows are cut into panels of `panel_rows`, columns into blocks of `col_block` (<= 8192),
  * and each (panel, block) cell stores its entries contiguously.  0 picks defaults. */
 int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block);
+/* Renumber the stored column ids by decreasing frequency inside this sample set (an internal
+ * layout change that speeds up the forward sweep on power-law data: the gathers of frequent
+ * columns are served from LDS).  Invisible at this boundary: every vector argument stays in the
+ * caller's numbering and admm_csr_download returns the original ids.  No counterpart in the
+ * reference. */
+int admm_csr_relabel_by_frequency(admm_csr *csr);
 /* Bytes of HBM held by this sample set. */
 int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t *transposed_bytes);
 int admm_csr_destroy(admm_csr *csr);

@@ -309,3 +309,61 @@ def test_sweeps_on_generated_set(ctx, oracle):
     close(f, f_ref)
     close(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
     dev.destroy()
+
+
+# ------------------------------------------------------------------------------------------------
+# frequency relabelling is invisible at the boundary
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("relabel_first", [False, True])
+def test_relabel_by_frequency_is_invisible(ctx, oracle, relabel_first):
+    dim = 40000                      # larger than the LDS-cached head of the gathered vector
+    raw = make_synth_csr(3000, dim, 50, seed=91, binary=False)
+    tr = oracle.translate(raw)
+    dev = upload(ctx, raw, dim)
+    if relabel_first:
+        dev.relabel_by_frequency().build_transposed(panel_rows=1000, col_block=1024)
+    else:
+        dev.build_transposed(panel_rows=1000, col_block=1024).relabel_by_frequency()
+    rowptr, col, val, label = dev.download()
+    np.testing.assert_array_equal(rowptr, tr.rowptr)
+    np.testing.assert_array_equal(col, tr.col)
+    np.testing.assert_array_equal(val, tr.val)
+    rng = np.random.default_rng(6)
+    x = rng.normal(0, 0.3, dim).astype(np.float32)
+    b = rng.normal(0, 0.05, dim).astype(np.float32)
+    z = rng.normal(0, 0.3, dim).astype(np.float32)
+    # metrics
+    s64, p_ref = oracle.logloss_sum_f64(tr, [x, b], want_p=True)
+    ll, auc, _ = dev.metrics([ctx.vec(dim, x), ctx.vec(dim, b)])
+    close(ll, s64 / tr.nrows)
+    close(auc, oracle.auc_from_scores(p_ref, tr.label, f64=True))
+    # objective / gradient
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, b, z, None, 0.3)
+    g = ctx.vec(dim)
+    f = dev.logistic_fg(ctx.vec(dim, x), g, offset=ctx.vec(dim, b), z=ctx.vec(dim, z), rho=0.3)
+    close(f, f_ref)
+    close(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
+    # sequential and mini-batch FTRL
+    for batch in (1, 1000):
+        hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+        oracle.ftrl_run(tr, hw, hz, hn, b, z, 0.05, 1.0, 0.1, 1.0, batch=batch)
+        w, zz, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+        dev.ftrl_pass(w, zz, n, ctx.vec(dim, b), ctx.vec(dim, z), 0.05, 1.0, 0.1, 1.0, batch=batch)
+        for got, ref in ((w, hw), (zz, hz), (n, hn)):
+            close(got.download(), ref, rtol=5e-5, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    dev.destroy()
+
+
+def test_gradient_is_reproducible(ctx):
+    """the transposed sweep adds in 64-bit fixed point: two evaluations agree bit for bit"""
+    dim = 1 << 15
+    dev = ctx.csr_synth(30000, dim, 60, seed=5).build_transposed(panel_rows=8192, col_block=2048)
+    x = ctx.vec(dim, np.random.default_rng(1).normal(0, 0.1, dim).astype(np.float32))
+    g = ctx.vec(dim)
+    f1 = dev.logistic_fg(x, g, rho=0.1)
+    g1 = g.download()
+    f2 = dev.logistic_fg(x, g, rho=0.1)
+    assert f1 == f2
+    np.testing.assert_array_equal(g1, g.download())
+    dev.destroy()

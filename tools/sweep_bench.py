@@ -11,15 +11,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--dim", type=int, default=1 << 22)
 ap.add_argument("--draws", type=float, default=131)
-ap.add_argument("--panel-rows", type=int, default=1 << 20)
+ap.add_argument("--panel-rows", type=int, default=0)
 ap.add_argument("--col-block", type=int, default=8192)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ablate", type=str, default="0")
+ap.add_argument("--no-relabel", action="store_true")
 args = ap.parse_args()
 
 ctx = capi.Context(0)
 s = ctx.csr_synth(args.rows, args.dim, args.draws, seed=1)
 s.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
+if not args.no_relabel:
+    s.relabel_by_frequency()
 x, g = ctx.vec(args.dim), ctx.vec(args.dim)
 import numpy as np
 x.upload(np.random.default_rng(0).normal(0, 0.05, args.dim).astype(np.float32))
