@@ -45,8 +45,7 @@ def build_lib(verbose=False):
     return LIB
 
 
-HOST_SOURCES = ["sample_set.cc", "ftrl.cc", "workers.cc", "master.cc", "metrics.cc", "arg_parser.cc",
-                "model_io.cc"]
+HOST_SOURCES = ["runtime.cc", "arg_parser.cc", "sample_set.cc", "solvers.cc", "model_io.cc"]
 HOST_MAINS = {"admm": "admm_main.cc", "ftrl": "ftrl_main.cc", "evan": "eval_main.cc"}
 
 

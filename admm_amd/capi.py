@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libadmm_hip.so")
 
 # every symbol include/admm_hip.h declares
 SYMBOLS = [
-    "admm_last_error", "admm_abi_version", "admm_ctx_create", "admm_ctx_destroy", "admm_sync",
+    "admm_last_error", "admm_abi_version", "admm_device_count", "admm_ctx_create", "admm_ctx_destroy", "admm_sync",
     "admm_timing_enable", "admm_timing_reset", "admm_timing_get",
     "admm_vec_alloc", "admm_vec_free", "admm_vec_zero", "admm_vec_copy", "admm_vec_upload",
     "admm_vec_download",
@@ -64,6 +64,7 @@ def load():
     L.admm_last_error.argtypes = []
     L.admm_abi_version.restype = i32
     sig = {
+        "admm_device_count": [C.POINTER(i32)],
         "admm_ctx_create": [i32, vp, C.POINTER(vp)],
         "admm_ctx_destroy": [vp],
         "admm_sync": [vp],

@@ -232,6 +232,14 @@ using namespace admm_impl;
 extern "C" const char *admm_last_error(void) { return g_last_error.c_str(); }
 extern "C" int admm_abi_version(void) { return 1; }
 
+extern "C" int admm_device_count(int *count) {
+  ADMM_REQUIRE(count, "admm_device_count: NULL argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return ADMM_OK;
+}
+
 extern "C" int admm_ctx_create(int device, void *stream, admm_ctx **out) {
   ADMM_REQUIRE(out != nullptr, "admm_ctx_create: out is NULL");
   int ndev = 0;

@@ -1,0 +1,143 @@
+// FtrlSolver, Worker, Master and Metrics on top of the C ABI.
+#include <cmath>
+
+#include "admm_host.h"
+
+using admm::DeviceVector;
+using admm::Runtime;
+
+namespace ftrl {
+
+FtrlSolver::FtrlSolver(real_t lambda_1, real_t lambda_2, real_t alpha_init, real_t beta_init, std::size_t dim_init)
+    : l_1_(lambda_1), l_2_(lambda_2), alpha_(alpha_init), beta_(beta_init), dim_(dim_init) {
+  weight_.resize(dim_);
+  mid_weight_.resize(dim_);
+  squared_sum_.resize(dim_);
+}
+
+void FtrlSolver::Init(::admm::FtrlConfig &params) {
+  l_1_ = params.l_1;
+  l_2_ = params.l_2;
+  alpha_ = params.alpha;
+  beta_ = params.beta;
+  dim_ = params.dim;
+  batch_ = params.ftrl_batch;
+  weight_.resize(dim_);  // zero-filled (src/ftrl.cc:43-51)
+  mid_weight_.resize(dim_);
+  squared_sum_.resize(dim_);
+}
+
+void FtrlSolver::Assign(const DeviceVector &x, const DeviceVector &y) {
+  mid_weight_ = x;
+  squared_sum_ = y;
+}
+
+void FtrlSolver::Run(SampleSet &train_set, SampleSet &, const DeviceVector &offset, const DeviceVector &reg_offset) {
+  ADMM_CHECK(train_set.device() != nullptr);
+  ADMM_CHECK(offset.size() == dim_ && reg_offset.size() == dim_);
+  ADMM_CALL(admm_ftrl_pass(train_set.device(), weight_.data(), mid_weight_.data(), squared_sum_.data(),
+                           offset.data(), reg_offset.data(), alpha_, beta_, l_1_, l_2_, batch_));
+}
+
+}  // namespace ftrl
+
+namespace admm {
+
+void Worker::InitWorker(std::size_t fdim) {
+  base_vec_.resize(fdim);
+  bias_vec_.resize(fdim);
+  langr_vec_.resize(fdim);
+  nt_vec_.resize(fdim);
+  zt_vec_.resize(fdim);
+  load = false;
+}
+
+// The x-update (src/workers.cc:51-87).  Parts are loaded on the first call and stay resident.
+void Worker::BaseUpdate(SampleSet &, SampleSet &test_set, const AdmmConfig &admm_params) {
+  if (parts_.empty()) {
+    const std::string train_name = admm_params.train_path + "/" + psid_ + "_aggregated/part-00000";
+    for (int part = 0; part < num_part_; ++part) {
+      parts_.emplace_back(new SampleSet);
+      ADMM_CHECK(parts_.back()->Initialize(train_name, part, num_part_, admm_params.dim));
+      if (admm_params.local_solver == "lbfgs")
+        parts_.back()->PrepareTransposed(0, 0, true);
+      else if (admm_params.ftrl_batch > 1)
+        parts_.back()->PrepareTransposed(admm_params.ftrl_batch, 0, true);
+    }
+  }
+  if (admm_params.local_solver == "lbfgs") {
+    // batch objective: logistic loss + y.(x - z) + rho/2 |x - z|^2, warm-started at the last x
+    ADMM_CHECK(parts_.size() == 1);
+    ADMM_CALL(admm_lbfgs_solve(parts_[0]->device(), base_vec_.data(), bias_vec_.data(),
+                               admm_params.global_weights.data(), langr_vec_.data(), admm_params.step_size,
+                               &admm_params.lbfgs, &last_solve_));
+    return;
+  }
+  FtrlConfig ftrl_params(admm_params);
+  ftrl_params.l_2 = 200;  // src/workers.cc:53-54
+  ftrl_params.l_1 = 1;
+  ftrl_params.ftrl_batch = admm_params.ftrl_batch;
+  ::ftrl::FtrlSolver ftrl_processor;
+  ftrl_processor.Init(ftrl_params);
+  ftrl_processor.squared_sum_ = nt_vec_;
+  ftrl_processor.mid_weight_ = zt_vec_;
+  for (auto &part : parts_)  // reg_offset = global weights; the dual term is not part of it (:59)
+    ftrl_processor.Run(*part, test_set, bias_vec_, admm_params.global_weights);
+  base_vec_ = ftrl_processor.weight_;
+  if (load) {
+    nt_vec_ = ftrl_processor.squared_sum_;
+    zt_vec_ = ftrl_processor.mid_weight_;
+    load = false;
+  }
+}
+
+void Worker::LangrangeUpdate(const AdmmConfig &admm_params) {
+  ADMM_CALL(admm_dual_update(Runtime::Get().ctx(), langr_vec_.data(), base_vec_.data(),
+                             admm_params.global_weights.data(), admm_params.step_size, langr_vec_.size()));
+}
+
+void Worker::GetWeights(AdmmConfig &admm_params, DeviceVector &out) const {
+  ADMM_CHECK(out.size() == base_vec_.size());
+  ADMM_CALL(admm_payload(Runtime::Get().ctx(), base_vec_.data(), langr_vec_.data(), admm_params.step_size, out.data(),
+                         out.size()));
+}
+
+bool Master::GlobalUpdate(const DeviceVector &workers, AdmmConfig &admm_params, int num_worker) {
+  return admm_global_update(Runtime::Get().ctx(), workers.data(), num_worker, admm_params.step_size,
+                            admm_params.global_var, admm_params.global_l1, admm_params.global_weights.data(),
+                            workers.size()) == ADMM_OK;
+}
+
+bool Master::Consensus(const DeviceVector &workers, AdmmConfig &admm_params, int num_worker, Worker &worker, double *r2,
+                       double *s2) {
+  return admm_consensus(Runtime::Get().ctx(), workers.data(), num_worker, admm_params.step_size,
+                        admm_params.global_var, admm_params.global_l1, worker.base_vec_.data(),
+                        worker.langr_vec_.data(), admm_params.global_weights.data(), workers.size(), r2,
+                        s2) == ADMM_OK;
+}
+
+}  // namespace admm
+
+void Metrics::Both(::admm::SampleSet &sample_set, std::vector<const DeviceVector *> &weights, real_t *loss,
+                   real_t *auc) {
+  ADMM_CHECK(sample_set.device() != nullptr && !weights.empty() && weights.size() <= 4);
+  const float *groups[4];
+  for (size_t i = 0; i < weights.size(); ++i) groups[i] = weights[i]->data();
+  double l = 0, a = 0;
+  ADMM_CALL(admm_metrics(sample_set.device(), groups, (int)weights.size(), loss ? &l : nullptr, auc ? &a : nullptr,
+                         nullptr));
+  if (loss) *loss = (real_t)l;
+  if (auc) *auc = (real_t)a;
+}
+
+Metrics::real_t Metrics::Auc(::admm::SampleSet &sample_set, std::vector<const DeviceVector *> &weights, bool) {
+  real_t a = 0;
+  Both(sample_set, weights, nullptr, &a);
+  return a;
+}
+
+Metrics::real_t Metrics::LogLoss(::admm::SampleSet &sample_set, std::vector<const DeviceVector *> &weights, bool) {
+  real_t l = 0;
+  Both(sample_set, weights, &l, nullptr);
+  return l;
+}

@@ -42,6 +42,7 @@ int admm_abi_version(void);
 /* Stands in for rabit::Init / rabit::Finalize as far as device set-up goes
  * (src/admm_allreduce.cpp:9,113).  `stream` is a hipStream_t to queue on, or NULL to let the
  * library create its own. */
+int admm_device_count(int *count);
 int admm_ctx_create(int device, void *stream, admm_ctx **out);
 int admm_ctx_destroy(admm_ctx *ctx);
 int admm_sync(admm_ctx *ctx);

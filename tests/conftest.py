@@ -69,3 +69,13 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+def write_libsvm(path, raw):
+    """raw Csr (no bias column) -> libsvm text"""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        for r in range(raw.nrows):
+            b, e = int(raw.rowptr[r]), int(raw.rowptr[r + 1])
+            feats = " ".join("%d:%.9g" % (int(raw.col[k]), float(raw.val[k])) for k in range(b, e))
+            f.write("%g %s\n" % (float(raw.label[r]), feats))

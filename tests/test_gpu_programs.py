@@ -1,0 +1,154 @@
+"""The C++ host programs (admm, ftrl, evan) end to end on small libsvm directories, against the
+CPU restatement of the reference's main loops: report lines, and the state files they write."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, make_synth_csr, write_libsvm
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(ROOT, "admm_amd", "bin")
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=110, env=e)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout
+
+
+def _read_sparse_sections(path):
+    sections, cur = [], None
+    for line in open(path):
+        line = line.strip()
+        if not line:
+            continue
+        if ":" not in line:
+            cur = np.zeros(int(line), np.float32)
+            sections.append(cur)
+        else:
+            i, v = line.split(":")
+            cur[int(i)] = np.float32(v)
+    return sections
+
+
+def test_admm_program_matches_reference_loop(tmp_path, oracle):
+    dim = 300
+    raw_train = make_synth_csr(1500, dim, 12, seed=101, binary=False)
+    raw_test = make_synth_csr(400, dim, 12, seed=102, binary=False)
+    write_libsvm(str(tmp_path / "train" / "A_aggregated" / "part-00000"), raw_train)
+    write_libsvm(str(tmp_path / "test" / "A_aggregated" / "part-00000"), raw_test)
+    os.makedirs(tmp_path / "out")
+    conf = tmp_path / "admm.conf"
+    conf.write_text("step_size = 0.01\nbias_var = 0.01\nglobal_var = 4\nftrl_alpha = 0.1\npasses = 3\n"
+                    "dim = %d\nA : 2\n" % dim)
+    out = _run([os.path.join(BIN, "admm"), str(conf), str(tmp_path / "train"), str(tmp_path / "test"),
+                str(tmp_path / "out")])
+    # the reference: 2 data parts of the same file, split by byte range
+    text = open(tmp_path / "train" / "A_aggregated" / "part-00000", "rb").read()
+    parts = [oracle.translate(oracle.parse_libsvm_text(text, p, 2)) for p in range(2)]
+    for p in parts:
+        p.dim = dim
+    test = oracle.translate(oracle.parse_libsvm(str(tmp_path / "test" / "A_aggregated" / "part-00000")))
+    cfg = oracle.AdmmConf(step_size=0.01, global_var=4, ftrl_alpha=0.1, passes=3, dim=dim, bias_var=0.01)
+    workers, zg, rec = oracle.admm_run([parts], [test], cfg)
+    lines = re.findall(r"^A \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out, flags=re.M)
+    assert len(lines) == 3
+    for (l, a, n), r in zip(lines, rec):
+        assert int(n) == 400
+        assert float(l) == pytest.approx(r["lines"][0][0], rel=2e-5)
+        assert float(a) == pytest.approx(r["lines"][0][1], rel=5e-5)
+    assert [int(x) for x in re.findall(r"^Finish (\d+)-th iteration$", out, flags=re.M)] == [0, 1, 2]
+    # state files (6 significant digits in the text)
+    x, bias, y, nt, zt = _read_sparse_sections(tmp_path / "out" / "admm_weight_A")
+    for got, ref in ((x, workers[0].x), (y, workers[0].y), (nt, workers[0].nt), (zt, workers[0].zt)):
+        assert got.shape[0] == dim
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    assert not bias.any()
+    g = open(tmp_path / "out" / "global_params_A").read().split("\n")
+    assert [float(v) for v in g[:4]] == [0.01, 4.0, 0.01, float(dim)]
+    zfile = np.zeros(dim, np.float32)
+    for line in g[4:]:
+        if line:
+            i, v = line.split(":")
+            zfile[int(i)] = np.float32(v)
+    np.testing.assert_allclose(zfile, zg, rtol=2e-5, atol=1e-9)
+    b = open(tmp_path / "out" / "A.bin").read().split("\n")
+    assert b[0].startswith("-1:")
+    thr = np.exp(np.float32(-6.0))
+    expect = [i - 1 for i in range(1, dim) if abs(workers[0].x[i]) > thr]
+    assert [int(l.split(":")[0]) for l in b[1:] if l] == expect
+    # warm start: a second run that loads the written state continues from it
+    out2 = _run([os.path.join(BIN, "admm"), str(conf), str(tmp_path / "train"), str(tmp_path / "test"),
+                 str(tmp_path / "out"), str(tmp_path / "out")])
+    wk = [oracle.WorkerState(dim)]
+    wk[0].x, wk[0].y, wk[0].nt, wk[0].zt = x.copy(), y.copy(), nt.copy(), zt.copy()
+    _, _, rec2 = oracle.admm_run([parts], [test], cfg, workers=wk, zg=zfile.copy())
+    lines2 = re.findall(r"^A \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out2, flags=re.M)
+    for (l, a, n), r in zip(lines2, rec2):
+        assert float(l) == pytest.approx(r["lines"][0][0], rel=5e-5)
+
+
+def test_admm_program_on_wtest_fixture(tmp_path):
+    """BASELINE config 0 plumbing on one rank: the reference's own one-row fixture"""
+    for d in ("train", "test"):
+        os.makedirs(tmp_path / d / "A_aggregated")
+        with open(tmp_path / d / "A_aggregated" / "part-00000", "w") as f:
+            f.write(open(os.path.join(GOLDEN, "wtest.libsvm")).read())
+    os.makedirs(tmp_path / "out")
+    conf = tmp_path / "admm.conf"
+    conf.write_text("step_size = 0.01\nbias_var = 0.01\nglobal_var = 4\nftrl_alpha = 0.1\npasses = 3\ndim = 6\n"
+                    "train_path = %s\ntest_path = %s\noutput_path = %s\nA : 1\n"
+                    % (tmp_path / "train", tmp_path / "test", tmp_path / "out"))
+    out = _run([os.path.join(BIN, "admm"), str(conf)])          # paths from the conf: `./admm admm.conf`
+    assert out.count("A | 0.6931472 | ") == 3
+    x, bias, y, nt, zt = _read_sparse_sections(tmp_path / "out" / "admm_weight_A")
+    assert not x.any() and not y.any()
+    assert nt[[0, 1, 3, 5]].tolist() == [0.25] * 4 and zt[[0, 1, 3, 5]].tolist() == [-0.5] * 4
+    assert open(tmp_path / "out" / "A.bin").read() == "-1:0\n"
+
+
+def test_ftrl_and_evan_programs(tmp_path, oracle):
+    dim = 200
+    raw_train = make_synth_csr(1200, dim, 10, seed=111)
+    raw_test = make_synth_csr(300, dim, 10, seed=112)
+    write_libsvm(str(tmp_path / "train" / "B_aggregated" / "part-00000"), raw_train)
+    write_libsvm(str(tmp_path / "test" / "B_aggregated" / "part-00000"), raw_test)
+    os.makedirs(tmp_path / "out")
+    conf = tmp_path / "ftrl.conf"
+    conf.write_text("train_path = %s/\ntest_path = %s/\noutput_path = %s/\nftrl_alpha = 0.01\nftrl_beta = 1\n"
+                    "l_1 = 0.4\nl_2 = 2.5\npasses = 2\ndim = %d\nB : 1\n"
+                    % (tmp_path / "train", tmp_path / "test", tmp_path / "out", dim))
+    out = _run([os.path.join(BIN, "ftrl"), str(conf)])
+    tr, te = oracle.translate(raw_train), oracle.translate(raw_test)
+    w, z, n, zero = (np.zeros(dim, np.float32) for _ in range(4))
+    expect = []
+    for _ in range(2):
+        oracle.ftrl_run(tr, w, z, n, zero, zero, 0.01, 1.0, 0.4, 2.5)
+        expect.append((oracle.logloss(te, [w]), oracle.auc(te, [w])))
+    lines = re.findall(r"^B \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out, flags=re.M)
+    assert len(lines) == 2
+    for (l, a, nrow), (el, ea) in zip(lines, expect):
+        assert int(nrow) == 300
+        assert float(l) == pytest.approx(el, rel=2e-5) and float(a) == pytest.approx(ea, rel=5e-5)
+    state = np.loadtxt(tmp_path / "out" / "ftrl_weight_B", dtype=np.float32)
+    assert state.shape == (dim, 3)
+    for k, ref in enumerate((w, z, n)):
+        np.testing.assert_allclose(state[:, k], ref, rtol=2e-5, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    first = open(tmp_path / "out" / "ftrl_weight_B").readline()
+    assert len(first.rstrip("\n")) == 51                           # three left-aligned 17-wide columns
+    b = open(tmp_path / "out" / "B.bin").read().split("\n")
+    assert b[0].startswith("1:") and len([l for l in b if l]) == dim
+    # evan on the dense weight file
+    wfile = tmp_path / "w.txt"
+    wfile.write_text(" ".join("%.9g" % v for v in w))
+    out = _run([os.path.join(BIN, "evan"), str(wfile), str(tmp_path / "train") + "/", str(tmp_path / "test") + "/",
+                "B_aggregated/part-00000"])
+    m = re.search(r"^test \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out, flags=re.M)
+    assert m and float(m.group(1)) == pytest.approx(expect[-1][0], rel=2e-5)
+    assert float(m.group(2)) == pytest.approx(expect[-1][1], rel=5e-5)
