@@ -1,0 +1,56 @@
+"""One process per GPU: rank bookkeeping, row sharding and the per-iteration sum all-reduce
+(rabit::Allreduce<op::Sum> at src/admm_allreduce.cpp:69 of the reference) on torch.distributed --
+RCCL over xGMI for device tensors (backend "nccl"), gloo for host tensors in CPU tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    """(rank, world, local_rank) from torch.distributed.run's environment, else the reference
+    launcher's (DMLC_TASK_ID / DMLC_NUM_WORKER of tracker.py / dmlc_local.py), else (0, 1, 0)."""
+    rank = int(os.environ.get("RANK", os.environ.get("DMLC_TASK_ID", "0")))
+    world = int(os.environ.get("WORLD_SIZE", os.environ.get("DMLC_NUM_WORKER", "1")))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, world, local
+
+
+def init(backend=None, device=None):
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_range(total_rows, rank, world):
+    """Rows [begin, end) of rank `rank`: contiguous, sizes differ by at most one."""
+    return total_rows * rank // world, total_rows * (rank + 1) // world
+
+
+def allreduce_sum_(t):
+    """In-place sum over ranks; a no-op for a single process (as rabit without a tracker)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def allreduce_max_(t):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def finalize():
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -84,19 +84,16 @@ def cpu_baseline(ctx, args, rho):
 def main():
     args = parse_args()
     import torch
-    import torch.distributed as dist
     from admm_amd import capi, driver
+    from admm_amd import dist as adist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = adist.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    adist.init("nccl", device=torch.device("cuda", local_rank))
 
     # one HIP stream for the library's kernels and for torch's collectives
     tstream = torch.cuda.Stream()
@@ -105,8 +102,7 @@ def main():
 
     # ---- the rank's shard -------------------------------------------------------------------
     rows_total = args.rows
-    r0 = rows_total * rank // world
-    r1 = rows_total * (rank + 1) // world
+    r0, r1 = adist.shard_range(rows_total, rank, world)
     t_gen = time.perf_counter()
     train = ctx.csr_synth(r1 - r0, args.dim, args.mean_nnz, seed=args.seed, row_offset=r0)
     train.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
@@ -129,16 +125,14 @@ def main():
     payload = capi.DeviceVec.from_ptr(ctx, payload_t.data_ptr(), args.dim)
 
     def allreduce(_buf):
-        if world > 1:
-            dist.all_reduce(payload_t, op=dist.ReduceOp.SUM)
+        adist.allreduce_sum_(payload_t)
 
     def step(last=False):
         return driver.admm_iteration(worker, master, [train], test, prm, zg, payload, allreduce,
                                      world, last)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        adist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -160,15 +154,9 @@ def main():
 
     # max time and total swept entries over ranks
     swept = float(train.nnz) * evals
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        s = torch.tensor([swept, float(train.nnz), float(evals)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        swept, nnz_total, evals_total = (float(v) for v in s.tolist())
-    else:
-        nnz_total, evals_total = float(train.nnz), float(evals)
+    dt = float(adist.allreduce_max_(torch.tensor([dt], dtype=torch.float64, device="cuda")).item())
+    s = adist.allreduce_sum_(torch.tensor([swept, float(train.nnz), float(evals)], dtype=torch.float64, device="cuda"))
+    swept, nnz_total, evals_total = (float(v) for v in s.tolist())
 
     if rank == 0:
         rows = r1 - r0
@@ -234,8 +222,7 @@ def main():
     train.destroy()
     test.destroy()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    adist.finalize()
 
 
 if __name__ == "__main__":
