@@ -25,7 +25,7 @@ SYMBOLS = [
     "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32",
 ]
 
-K_FORWARD, K_TRANSPOSED, K_FTRL_SEQ, K_ELEMENTWISE = 0, 1, 2, 3
+K_FORWARD, K_TRANSPOSED, K_FTRL_SEQ, K_ELEMENTWISE, K_FORWARD_EVAL = 0, 1, 2, 3, 4
 
 
 class AdmmError(RuntimeError):

@@ -64,8 +64,8 @@ struct admm_ctx {
   bool timing = false;
   std::vector<admm_impl::TimingSlot> pending;
   std::vector<admm_impl::TimingSlot> free_slots;
-  double k_ms[ADMM_K_COUNT] = {0, 0, 0, 0};
-  uint64_t k_launches[ADMM_K_COUNT] = {0, 0, 0, 0};
+  double k_ms[ADMM_K_COUNT] = {};
+  uint64_t k_launches[ADMM_K_COUNT] = {};
   // L-BFGS workspace (lazily sized)
   float *lbfgs_ws = nullptr;
   uint64_t lbfgs_ws_floats = 0;

@@ -58,6 +58,7 @@ constexpr size_t kFwLds = sizeof(float) * (kFwChunk + kFwHot) + sizeof(unsigned 
 // by decreasing frequency (power-law data: a few thousand columns hold most entries), the
 // gathered vector `wsum` is stored in that order, and its first kFwHot entries are kept in LDS,
 // where a gather is an order of magnitude cheaper.
+template <int MODE>
 __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   extern __shared__ unsigned long long fw_lds[];
   unsigned long long *rp = fw_lds;                                      // [kFwRows + 1]
@@ -121,12 +122,12 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       const uint64_t myrow = rbase + trow;
       const float m = rowsum;
       const float lab = a.label[myrow];
-      if (a.mode == FWD_EVAL) {
+      if (MODE == FWD_EVAL) {
         // src/metrics.cc:104-105: double predict, -log p / -log(1-p)
         const double pd = 1.0f / (1 + exp(-(double)clamp35(m)));
         a.out[myrow] = (float)pd;
         acc0 += lab > 0 ? -log(pd) : -log(1 - pd);
-      } else if (a.mode == FWD_LBFGS) {
+      } else if (MODE == FWD_LBFGS) {
         const float t = lab > 0 ? 1.0f : 0.0f;
         const float loss = log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f));
         const float res = 1.0f / (1.0f + expf(-m)) - t;
@@ -212,15 +213,22 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   if (const char *ab = getenv("ADMM_ABLATE")) a.ablate = atoi(ab) & 0xFF;
   static bool raised = false;
   if (!raised) {
-    ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_forward),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds));
+    for (const void *fn : {reinterpret_cast<const void *>(&k_forward<FWD_EVAL>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_LBFGS>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_FTRL>)})
+      ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds));
     raised = true;
   }
   const uint64_t ntiles = (r1 - r0 + kFwRows - 1) / kFwRows;
   const int grid = grid_for(ntiles * kFwThreads, kFwThreads, ctx->cu_count);
   *nblocks_out = grid;
-  KernelTimer t(ctx, ADMM_K_FORWARD);
-  hipLaunchKernelGGL(k_forward, dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
+  KernelTimer t(ctx, mode == FWD_EVAL ? ADMM_K_FORWARD_EVAL : ADMM_K_FORWARD);
+  if (mode == FWD_EVAL)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FWD_EVAL>), dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
+  else if (mode == FWD_LBFGS)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FWD_LBFGS>), dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FWD_FTRL>), dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
   ADMM_HIP_CHECK(hipGetLastError());
   return ADMM_OK;
 }

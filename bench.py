@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2] at N=1, configs[3] at N=8): ADMM-LR with the L1+L2 consensus
+Workload: ADMM-LR with the L1+L2 consensus
 update on a synthetic power-law set of 100M rows x 2^22 features, ~100 stored entries per row,
 row-sharded over the N GPUs (the same 100M rows for every N: strong scaling).  One step = one
 ADMM iteration on every rank: local x-update (L-BFGS on logistic loss + y.(x-z) + rho/2|x-z|^2,
@@ -168,26 +168,26 @@ def main():
         tr_bytes = 8.0 * tnnz + 4.0 * rows + 4.0 * args.dim
         fwd_avg = fwd_ms / max(fwd_n, 1) * 1e-3
         tr_avg = tr_ms / max(tr_n, 1) * 1e-3
-        # the forward sweep also runs once per step on the test shard: count train-shard launches
         kernels = {
-            "forward_csr_sweep": {"avg_ms": fwd_avg * 1e3, "launches": fwd_n,
-                                  "note": "average includes the small test-shard launch of each step"},
-            "transposed_block_sweep": {"avg_ms": tr_avg * 1e3, "launches": tr_n,
+            "forward_csr_sweep": {"avg_ms": fwd_avg * 1e3, "launches": fwd_n, "algorithmic_bytes": fwd_bytes,
+                                  "achieved_GBs": fwd_bytes / fwd_avg / 1e9 if fwd_avg > 0 else None},
+            "transposed_block_sweep": {"avg_ms": tr_avg * 1e3, "launches": tr_n, "algorithmic_bytes": tr_bytes,
                                        "achieved_GBs": tr_bytes / tr_avg / 1e9 if tr_avg > 0 else None},
         }
-        # per-launch figure for the forward sweep over the train shard only
-        test_rows_frac = float(test.nnz) / float(train.nnz)
-        fwd_train_launches = evals
-        if fwd_n > 0 and fwd_train_launches > 0:
-            fwd_train_avg = (fwd_ms * 1e-3) / (fwd_train_launches + args.steps * test_rows_frac)
-        else:
-            fwd_train_avg = 0.0
-        kernels["forward_csr_sweep"]["train_launch_ms"] = fwd_train_avg * 1e3
-        kernels["forward_csr_sweep"]["achieved_GBs"] = fwd_bytes / fwd_train_avg / 1e9 if fwd_train_avg else None
-        if tr_ms >= fwd_ms:
-            dom, ach = "transposed_block_sweep", tr_bytes / tr_avg / 1e9
-        else:
-            dom, ach = "forward_csr_sweep", fwd_bytes / fwd_train_avg / 1e9
+        dom = "transposed_block_sweep" if tr_ms >= fwd_ms else "forward_csr_sweep"
+        ach = kernels[dom]["achieved_GBs"]
+        # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE of this
+        # same command, corrected as that file explains); only for the workload they were taken on
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic_c3.json")
+        if os.path.exists(tfile):
+            pmc = json.load(open(tfile))
+            wl = pmc.get("workload", {})
+            if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus")) == (rows_total, args.dim, world):
+                sym = "k_transposed<false>" if dom == "transposed_block_sweep" else "k_forward<1>"
+                for name, rec in pmc["kernels"].items():
+                    if sym in name:
+                        traffic, traffic_src = rec["traffic_bytes"], "profiles/pmc_traffic_c3.json"
         out = {
             "metric": "nnz/sec per ADMM iteration + % HBM roofline at 1/2/4/8 MI355X",
             "value": swept / dt,
@@ -213,7 +213,9 @@ def main():
                 "last_residuals": [last_rec["r2"], last_rec["s2"]] if last_rec else None,
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernels": kernels},
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes": kernels[dom]["algorithmic_bytes"],
+                         "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, args, float(prm.step_size))

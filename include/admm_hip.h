@@ -49,11 +49,12 @@ int admm_sync(admm_ctx *ctx);
 
 /* Per-kernel device timing with HIP events on the context's stream (profiling aid, no
  * counterpart in the reference).  kernel ids: ADMM_K_*. */
-#define ADMM_K_FORWARD 0    /* row-parallel CSR sweep (margins, sigmoid, loss) */
+#define ADMM_K_FORWARD 0    /* row-parallel CSR sweep of a training step (margins, residual, loss) */
 #define ADMM_K_TRANSPOSED 1 /* column-block sweep (X^T r) */
 #define ADMM_K_FTRL_SEQ 2   /* exact sequential FTRL pass */
 #define ADMM_K_ELEMENTWISE 3
-#define ADMM_K_COUNT 4
+#define ADMM_K_FORWARD_EVAL 4 /* the same sweep in its prediction / logloss form */
+#define ADMM_K_COUNT 5
 int admm_timing_enable(admm_ctx *ctx, int on);
 int admm_timing_reset(admm_ctx *ctx);
 int admm_timing_get(admm_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);

@@ -95,7 +95,7 @@ def test_admm_program_matches_reference_loop(tmp_path, oracle):
 
 
 def test_admm_program_on_wtest_fixture(tmp_path):
-    """BASELINE config 0 plumbing on one rank: the reference's own one-row fixture"""
+    """the program on the reference's own one-row fixture (test/wtest.libsvm), one rank"""
     for d in ("train", "test"):
         os.makedirs(tmp_path / d / "A_aggregated")
         with open(tmp_path / d / "A_aggregated" / "part-00000", "w") as f:
