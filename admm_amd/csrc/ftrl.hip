@@ -41,54 +41,102 @@ __device__ inline float seq_sigmoid(float margin) {
   return (float)(1.0 / (1 + exp(-(double)m)));
 }
 
-// SERIAL = false: one lane per stored coordinate (requires rows without repeated columns).
-// SERIAL = true : lane 0 walks the row element by element, for rows that store a column twice
-//                 (the reference then applies the update twice in sequence).
-template <bool SERIAL>
-__global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
-  const int lane = threadIdx.x;
+// Lane-serial variant for sets in which some row stores a column twice: the reference then applies
+// the update twice in sequence, so lane 0 walks every row element by element.
+__global__ void __launch_bounds__(64) k_ftrl_seq_serial(SeqArgs a) {
+  if (threadIdx.x != 0) return;
   float *w = a.w, *z = a.z, *n = a.n;
   for (uint64_t r = 0; r <= a.nrows; ++r) {
-    // the extra trip (r == nrows) is the trailing Predict on the last row (src/ftrl.cc:140-141)
-    const bool tail = r == a.nrows;
+    const bool tail = r == a.nrows;  // trailing Predict on the last row (src/ftrl.cc:140-141)
     const uint64_t row = tail ? a.nrows - 1 : r;
     const uint64_t b = a.rowptr[row];
     const uint32_t len = (uint32_t)(a.rowptr[row + 1] - b);
-    if (SERIAL) {
-      if (lane == 0) {
-        for (uint32_t k = 0; k < len; ++k) {
-          const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
-          w[j] = seq_weight(z[j], n[j], a.reg[j], a.alpha, a.beta, a.l1, a.l2);
-        }
-        if (!tail) {
-          float sw = 0.0f, so = 0.0f;
-          for (uint32_t k = 0; k < len; ++k) {
-            const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
-            const float v = a.val ? a.val[b + k] : 1.0f;
-            sw += w[j] * v;
-            so += a.offset[j] * v;
-          }
-          const float p = seq_sigmoid(sw + so);
-          const int y = a.label[row] > 0 ? 1 : 0;
-          const float g = p - y;
-          for (uint32_t k = 0; k < len; ++k) {
-            const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
-            const double sigma = (sqrt((double)(n[j] + g * g)) - sqrt((double)n[j])) / (double)a.alpha;
-            z[j] = (float)((double)z[j] + ((double)g - sigma * (double)w[j]));
-            n[j] = n[j] + g * g;
-          }
-        }
+    for (uint32_t k = 0; k < len; ++k) {
+      const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
+      w[j] = seq_weight(z[j], n[j], a.reg[j], a.alpha, a.beta, a.l1, a.l2);
+    }
+    if (tail) break;
+    float sw = 0.0f, so = 0.0f;
+    for (uint32_t k = 0; k < len; ++k) {
+      const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
+      const float v = a.val ? a.val[b + k] : 1.0f;
+      sw += w[j] * v;
+      so += a.offset[j] * v;
+    }
+    const float p = seq_sigmoid(sw + so);
+    const int y = a.label[row] > 0 ? 1 : 0;
+    const float g = p - y;
+    for (uint32_t k = 0; k < len; ++k) {
+      const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
+      const double sigma = (sqrt((double)(n[j] + g * g)) - sqrt((double)n[j])) / (double)a.alpha;
+      z[j] = (float)((double)z[j] + ((double)g - sigma * (double)w[j]));
+      n[j] = n[j] + g * g;
+    }
+  }
+}
+
+constexpr int kSeqAhead = 4;  // rows whose stored entries are fetched ahead of the row being solved
+
+// One wavefront walks the rows in order; lane k owns the k-th stored coordinate of the row.
+// Everything that does not depend on the solver state is fetched ahead: row pointers and labels a
+// block of 64 rows at a time (one coalesced load, then lane shuffles), column ids and values
+// kSeqAhead rows ahead into registers.  What remains on the per-row chain is the gather of the
+// touched state, the closed-form weights, one wave reduction, the sigmoid, and the scatter.
+__global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
+  const int lane = threadIdx.x;
+  float *w = a.w, *z = a.z, *n = a.n;
+  const uint64_t total = a.nrows + 1;  // + the trailing Predict on the last row
+  unsigned long long rp_lo = 0, rp_hi = 0;
+  float lab_blk = 0.0f;
+  uint32_t pcol[kSeqAhead];
+  float pval[kSeqAhead];
+  auto row_of = [&](uint64_t t) { return t < a.nrows ? t : a.nrows - 1; };
+  // direct (not block-cached) fetch used for the look-ahead rows
+  auto fetch = [&](uint64_t t, uint32_t &c, float &v) {
+    c = 0;
+    v = 0.0f;
+    if (t >= total) return;
+    const uint64_t row = row_of(t);
+    const uint64_t b = a.rowptr[row];
+    const uint32_t len = (uint32_t)(a.rowptr[row + 1] - b);
+    if ((uint32_t)lane < len) {
+      c = a.col[b + lane];
+      v = a.val ? a.val[b + lane] : 1.0f;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < kSeqAhead; ++u) fetch(u, pcol[u], pval[u]);
+  for (uint64_t t0 = 0; t0 < total; t0 += kSeqAhead) {
+#pragma unroll
+    for (int u = 0; u < kSeqAhead; ++u) {
+      const uint64_t t = t0 + u;
+      if (t >= total) break;
+      const bool tail = t == a.nrows;
+      const uint64_t row = row_of(t);
+      if ((row & 63) == 0 || t == 0 || tail) {
+        const uint64_t rb = row & ~63ull;
+        const uint64_t rr = rb + lane < a.nrows ? rb + lane : a.nrows - 1;
+        rp_lo = a.rowptr[rr];
+        rp_hi = a.rowptr[rr + 1];
+        lab_blk = a.label[rr];
       }
-    } else {
+      const int rl = (int)(row & 63);
+      const unsigned long long b = __shfl(rp_lo, rl, 64);
+      const uint32_t len = (uint32_t)(__shfl(rp_hi, rl, 64) - b);
+      const float lab = __shfl(lab_blk, rl, 64);
+      // this row's first 64 entries arrived kSeqAhead rows ago; start the fetch for a later row
+      const uint32_t c0 = pcol[u];
+      const float v0 = pval[u];
+      fetch(t + kSeqAhead, pcol[u], pval[u]);
       float sw = 0.0f, so = 0.0f;
-      // first (usually only) chunk stays in registers for the update
       uint32_t j0 = 0;
       float z0 = 0.0f, n0 = 0.0f, w0 = 0.0f;
       for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t k = base + lane;
         if (k < len) {
-          const uint32_t j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
-          const float v = a.val ? a.val[b + k] : 1.0f;
+          uint32_t j = base == 0 ? c0 : a.col[b + k];
+          if (a.perm) j = a.perm[j];
+          const float v = base == 0 ? v0 : (a.val ? a.val[b + k] : 1.0f);
           const float zj = z[j], nj = n[j];
           const float wj = seq_weight(zj, nj, a.reg[j], a.alpha, a.beta, a.l1, a.l2);
           w[j] = wj;
@@ -104,7 +152,7 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
       }
       if (!tail) {
         const float p = seq_sigmoid(wave_sum(sw) + wave_sum(so));
-        const int y = a.label[row] > 0 ? 1 : 0;
+        const int y = lab > 0 ? 1 : 0;
         const float g = p - y;
         const float g2 = g * g;
         for (uint32_t base = 0; base < len; base += 64) {
@@ -118,7 +166,8 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
               nj = n0;
               wj = w0;
             } else {
-              j = a.perm ? a.perm[a.col[b + k]] : a.col[b + k];
+              j = a.col[b + k];
+              if (a.perm) j = a.perm[j];
               zj = z[j];
               nj = n[j];
               wj = w[j];
@@ -129,10 +178,9 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
           }
         }
       }
+      // the next row's gathers (other lanes) must observe this row's stores
+      __threadfence_block();
     }
-    // the next row's gathers (other lanes) must observe this row's stores
-    __threadfence_block();
-    if (a.nrows == 0) break;
   }
 }
 
@@ -158,9 +206,9 @@ int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const floa
   a.l2 = l2;
   KernelTimer t(ctx, ADMM_K_FTRL_SEQ);
   if (csr->has_dup_cols)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ftrl_seq<true>), dim3(1), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_ftrl_seq_serial, dim3(1), dim3(64), 0, ctx->stream, a);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ftrl_seq<false>), dim3(1), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_ftrl_seq, dim3(1), dim3(64), 0, ctx->stream, a);
   ADMM_HIP_CHECK(hipGetLastError());
   return ADMM_OK;
 }

@@ -1,0 +1,31 @@
+"""Development aid: time the FTRL pass (exact sequential and mini-batch) on a synthetic set."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from admm_amd import capi  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=1_000_000)
+ap.add_argument("--dim", type=int, default=1 << 20)
+ap.add_argument("--draws", type=float, default=47)
+ap.add_argument("--batch", type=str, default="1")
+args = ap.parse_args()
+
+ctx = capi.Context(0)
+s = ctx.csr_synth(args.rows, args.dim, args.draws, seed=1)
+print("rows %d nnz %d (%.1f per row)" % (s.nrows, s.nnz, s.nnz / s.nrows), flush=True)
+for b in [int(x) for x in args.batch.split(",")]:
+    if b > 1:
+        s.build_transposed(panel_rows=b)
+    w, z, n, off, reg = (ctx.vec(args.dim) for _ in range(5))
+    ctx.sync()
+    t0 = time.perf_counter()
+    s.ftrl_pass(w, z, n, off, reg, 0.01, 1.0, 0.4, 2.5, batch=b)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ll, auc, _ = s.metrics([w])
+    print("batch %-8d %.3f s  %.3e nnz/s  %.3e rows/s   train logloss %.5f auc %.5f"
+          % (b, dt, s.nnz / dt, s.nrows / dt, ll, auc), flush=True)
