@@ -59,6 +59,7 @@ struct TBuildArgs {
   uint64_t nrows, panel_rows;
   uint32_t col_block, nblocks;
   int skip_bias;
+  int hot_dense;  // entries held by the per-row hot mask (relabelled id < 64, value 1) are left out
   unsigned long long *cell_count;   // pass 1: entries per cell
   unsigned long long *cell_cursor;  // pass 2: next free slot per cell (starts at tptr[cell])
   uint32_t *trow;
@@ -87,6 +88,7 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
     const uint64_t kb = a.rowptr[r0], ke = a.rowptr[r1];
     for (uint64_t k = kb + threadIdx.x; k < ke; k += 256) {
       uint32_t c = a.col[k];
+      if (a.hot_dense && c < 64u && (!a.val || a.val[k] == 1.0f)) continue;
       if (a.perm) c = a.perm[c];
       if (a.skip_bias && c == 0) continue;
       atomicAdd(&cnt[c / a.col_block], 1u);
@@ -110,6 +112,7 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
         const uint64_t b = a.rowptr[r], e = a.rowptr[r + 1];
         for (uint64_t k = b + sub; k < e; k += 16) {
           uint32_t c = a.col[k];
+          if (a.hot_dense && c < 64u && (!a.val || a.val[k] == 1.0f)) continue;
           if (a.perm) c = a.perm[c];
           if (a.skip_bias && c == 0) continue;
           const uint32_t blk = c / a.col_block;
@@ -306,6 +309,67 @@ __global__ void __launch_bounds__(256) k_relabel(uint32_t *__restrict__ col, con
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += stride) col[i] = inv[col[i]];
 }
 
+// Split every row of a relabelled set into a 64-bit mask (unit-valued entries whose id is below 64)
+// and the rest, kept in order.  FILL = false counts the rest per row, FILL = true writes it.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ rowptr,
+                                                 const uint32_t *__restrict__ col,
+                                                 const float *__restrict__ val, uint64_t nrows,
+                                                 uint64_t *__restrict__ rowlen,
+                                                 const uint64_t *__restrict__ crowptr,
+                                                 uint32_t *__restrict__ ccol, float *__restrict__ cval,
+                                                 uint64_t *__restrict__ hmask) {
+  // one 16-lane group per row
+  const int lane = threadIdx.x & 63, sub = threadIdx.x & 15, gshift = lane & 48;
+  const uint64_t grp = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const uint64_t ngrp = ((uint64_t)gridDim.x * 256) >> 4;
+  const uint64_t nrounds = (nrows + ngrp - 1) / ngrp;  // wave-uniform trip count (ballots inside)
+  for (uint64_t it = 0; it < nrounds; ++it) {
+    const uint64_t r = grp + it * ngrp;
+    const bool live = r < nrows;
+    const uint64_t b = live ? rowptr[r] : 0, e = live ? rowptr[r + 1] : 0;
+    uint64_t out = FILL && live ? crowptr[r] : 0;
+    uint32_t mlo = 0, mhi = 0, ncold = 0;
+    const uint64_t trips = (e - b + 15) / 16;
+    uint64_t maxtrips = trips;
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t o = __shfl_xor((unsigned long long)maxtrips, off, 64);
+      maxtrips = o > maxtrips ? o : maxtrips;
+    }
+    for (uint64_t tr = 0; tr < maxtrips; ++tr) {
+      const uint64_t k = b + tr * 16 + sub;
+      const bool have = live && k < e;
+      const uint32_t c = have ? col[k] : 0xFFFFFFFFu;
+      const float v = have ? (val ? val[k] : 1.0f) : 0.0f;
+      const bool hot = have && c < 64u && v == 1.0f;
+      const bool cold = have && !hot;
+      if (hot) {
+        if (c < 32u) mlo |= 1u << c;
+        else mhi |= 1u << (c - 32u);
+      }
+      const unsigned long long cm = __ballot(cold);
+      const uint32_t gm = (uint32_t)((cm >> gshift) & 0xFFFFu);
+      if (FILL && cold) {
+        const uint64_t pos = out + __popc(gm & ((1u << sub) - 1u));
+        ccol[pos] = c;
+        cval[pos] = v;
+      }
+      out += __popc(gm);
+      ncold += __popc(gm);
+    }
+    if (!FILL) {
+      for (int off = 8; off > 0; off >>= 1) {
+        mlo |= __shfl_xor(mlo, off, 64);
+        mhi |= __shfl_xor(mhi, off, 64);
+      }
+      if (live && sub == 0) {
+        rowlen[r] = ncold;
+        hmask[r] = ((uint64_t)mhi << 32) | mlo;
+      }
+    }
+  }
+}
+
 int ensure_rowbuf(admm_csr *csr) {
   if (csr->d_rowbuf || csr->nrows == 0) return ADMM_OK;
   ADMM_HIP_CHECK(hipMalloc(&csr->d_rowbuf, sizeof(float) * csr->nrows));
@@ -339,7 +403,7 @@ static void free_csr(admm_csr *c) {
   }
   void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_tptr,
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask,
-                  c->d_wsum,   c->d_perm, c->d_inv};
+                  c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_crowptr, c->d_ccol, c->d_cval};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;
@@ -533,8 +597,45 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
                      csr->d_col, csr->d_inv, csr->nnz);
   RL_CHECK(hipGetLastError());
   RL_CHECK(hipStreamSynchronize(ctx->stream));
-#undef RL_CHECK
   cleanup();
+  count = count_sorted = ids = nullptr;
+  tmp = nullptr;
+  // compact form for the forward sweep (sets whose rows never repeat a column, dim >= 64)
+  if (!csr->has_dup_cols && dim >= 64 && csr->nrows > 0) {
+    const uint64_t n = csr->nrows;
+    uint64_t *rowlen = nullptr;
+    RL_CHECK(hipMalloc(&rowlen, sizeof(uint64_t) * (n + 1)));
+    RL_CHECK(hipMemsetAsync(rowlen, 0, sizeof(uint64_t) * (n + 1), ctx->stream));
+    RL_CHECK(hipMalloc(&csr->d_hmask, sizeof(uint64_t) * n));
+    RL_CHECK(hipMalloc(&csr->d_crowptr, sizeof(uint64_t) * (n + 1)));
+    const int cgrid = grid_for(n * 16, 256, ctx->cu_count * 8);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact<false>), dim3(cgrid), dim3(256), 0, ctx->stream, csr->d_rowptr,
+                       csr->d_col, csr->d_val, n, rowlen, nullptr, nullptr, nullptr, csr->d_hmask);
+    size_t sbytes = 0;
+    hipError_t se = hipcub::DeviceScan::ExclusiveSum(nullptr, sbytes, rowlen, csr->d_crowptr, (int64_t)(n + 1), ctx->stream);
+    void *stmp = nullptr;
+    if (se == hipSuccess) se = hipMalloc(&stmp, std::max<size_t>(sbytes, 16));
+    if (se == hipSuccess)
+      se = hipcub::DeviceScan::ExclusiveSum(stmp, sbytes, rowlen, csr->d_crowptr, (int64_t)(n + 1), ctx->stream);
+    uint64_t total = 0;
+    if (se == hipSuccess)
+      se = hipMemcpyAsync(&total, csr->d_crowptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (se == hipSuccess) se = hipStreamSynchronize(ctx->stream);
+    if (stmp) hipFree(stmp);
+    hipFree(rowlen);
+    RL_CHECK(se);
+    csr->cnnz = total;
+    RL_CHECK(hipMalloc(&csr->d_ccol, sizeof(uint32_t) * (total + 8)));
+    RL_CHECK(hipMalloc(&csr->d_cval, sizeof(float) * (total + 8)));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact<true>), dim3(cgrid), dim3(256), 0, ctx->stream, csr->d_rowptr,
+                       csr->d_col, csr->d_val, n, nullptr, csr->d_crowptr, csr->d_ccol, csr->d_cval, nullptr);
+    RL_CHECK(hipGetLastError());
+    RL_CHECK(hipStreamSynchronize(ctx->stream));
+    csr->hot_dense = true;
+  }
+#undef RL_CHECK
+  // a transposed copy built earlier still holds the entries the mask now covers: rebuild it
+  if (csr->has_t && csr->hot_dense) return admm_csr_build_transposed(csr, csr->panel_rows, csr->col_block);
   return ADMM_OK;
 }
 
@@ -587,7 +688,8 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   a.panel_rows = panel_rows;
   a.col_block = col_block;
   a.nblocks = csr->nblocks;
-  a.skip_bias = csr->has_bias ? 1 : 0;
+  a.skip_bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
+  a.hot_dense = csr->hot_dense ? 1 : 0;
   a.cell_count = d_cnt;
   const uint64_t chunks = csr->npanels * ((panel_rows + kChunkRows - 1) / kChunkRows);
   const int grid = grid_for(chunks * 256, 256, ctx->cu_count * 8);
@@ -607,7 +709,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   }
   csr->h_tptr[ncells] = run;
   csr->tnnz = run;
-  const uint64_t expect = csr->has_bias ? csr->nnz - csr->nrows : csr->nnz;
+  const uint64_t expect = csr->hot_dense ? csr->cnnz : (csr->has_bias ? csr->nnz - csr->nrows : csr->nnz);
   if (run != expect) {
     hipFree(d_cnt);
     set_error("admm_csr_build_transposed: counted %llu entries, expected %llu",

@@ -87,6 +87,13 @@ struct admm_csr {
   float *d_wsum = nullptr;    // dim floats: the vector the forward sweep gathers (relabelled order)
   // columns relabelled by decreasing frequency: d_col holds NEW ids; perm: new -> old, inv: old -> new
   uint32_t *d_perm = nullptr, *d_inv = nullptr;
+  // compact row-major form used by the forward sweep of a relabelled set: per row a 64-bit mask of
+  // its unit-valued entries in the 64 most frequent columns, and the remaining entries as CSR
+  bool hot_dense = false;
+  uint64_t *d_hmask = nullptr, *d_crowptr = nullptr;
+  uint32_t *d_ccol = nullptr;
+  float *d_cval = nullptr;
+  uint64_t cnnz = 0;
   uint32_t fwd_lpr = 16;      // lanes per row of the forward sweep
   // transposed (column-block) copy
   bool has_t = false;

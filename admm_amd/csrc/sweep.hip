@@ -29,6 +29,13 @@ struct FwdArgs {
   int mode;
   int ablate;  // development switches, 0 in normal operation
   uint32_t nhot;  // leading entries of w[0] cached in LDS
+  // compact sets: per-row mask of unit entries in columns 0..63 (nullptr otherwise), and where the
+  // per-column sums of those columns go (64-bit fixed point accumulators indexed by original id)
+  const uint64_t *hmask;
+  const uint32_t *perm;
+  unsigned long long *g1, *g2;
+  uint32_t *gmask;
+  float scale;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +52,8 @@ constexpr int kFwRows = 256;
 constexpr int kFwChunk = 16384;
 constexpr int kFwHot = 16384;
 constexpr int kFwLanesPerRow = kFwThreads / kFwRows;  // 4
-constexpr size_t kFwLds = sizeof(float) * (kFwChunk + kFwHot) + sizeof(unsigned long long) * (kFwRows + 2) + 64;
+constexpr size_t kFwLds = sizeof(float) * (kFwChunk + kFwHot + 8 * 256) +
+                          sizeof(unsigned long long) * (2 * (kFwRows + 2) + 4 * kFwRows) + 64;
 
 // CSR-stream forward sweep.  The stored entries of a tile's rows are one contiguous range of
 // col/val, which all threads stream with 16-byte loads (four entries per lane per load, several
@@ -61,10 +69,16 @@ constexpr size_t kFwLds = sizeof(float) * (kFwChunk + kFwHot) + sizeof(unsigned 
 template <int MODE>
 __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   extern __shared__ unsigned long long fw_lds[];
-  unsigned long long *rp = fw_lds;                                      // [kFwRows + 1]
-  float *prod = reinterpret_cast<float *>(fw_lds + kFwRows + 2);        // [kFwChunk]
+  unsigned long long *rp0 = fw_lds;                                     // [2][kFwRows + 2] row pointers
+  unsigned long long *mask0 = rp0 + 2 * (kFwRows + 2);                  // [2][kFwRows] hot masks
+  unsigned long long *rfx_s = mask0 + 2 * kFwRows;                      // [kFwRows] residual, fixed point
+  unsigned long long *rfx2_s = rfx_s + kFwRows;                         // [kFwRows] its square (FTRL form)
+  float *prod = reinterpret_cast<float *>(rfx2_s + kFwRows);            // [kFwChunk]
   float *hot = prod + kFwChunk;                                         // [kFwHot]
+  float *tab = hot + kFwHot;                                            // [8][256] byte -> sum of hot weights
   __shared__ double shred[kFwThreads / 64];
+  __shared__ unsigned long long hsum[kFwThreads / 64][64];
+  constexpr int H = kFwChunk / (4 * kFwThreads);  // 16-byte loads per thread and chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int trow = tid / kFwLanesPerRow, q = tid % kFwLanesPerRow;
@@ -72,49 +86,124 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   const uint64_t ntiles = (nrows + kFwRows - 1) / kFwRows;
   const float *__restrict__ wsum = a.w[0];
   const uint32_t nhot = a.nhot;
+  const bool dense = a.hmask != nullptr;
   for (uint32_t j = tid; j < nhot; j += kFwThreads) hot[j] = wsum[j];
+  if (dense) {
+    // tab[g][byte] = sum of the weights of columns 8g .. 8g+7 selected by the bits of `byte`
+    __syncthreads();
+    for (int i = tid; i < 8 * 256; i += kFwThreads) {
+      const int g = i >> 8, byte = i & 255;
+      float t = 0.0f;
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit)
+        if (byte & (1 << bit)) t += hot[8 * g + bit];
+      tab[i] = t;
+    }
+  }
   double acc0 = 0, acc1 = 0;
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // per-lane sums of the 64 mask columns over the rows this wave has seen (lane k <-> column k)
+  unsigned long long h1 = 0, h2 = 0, hseen = 0;
+
+  // streamed entries of one chunk, four per 16-byte load, held in registers between the load and
+  // the gather so that the next tile's stream is in flight while this tile is being finished
+  u32x4 pc[H];
+  f32x4 pv[H];
+#define FW_ISSUE(CB, EE)                                                                              \
+  _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
+    const unsigned long long k_ = (CB) + (unsigned long long)h * (4 * kFwThreads) + (unsigned long long)tid * 4; \
+    if (k_ < (EE)) {                                                                                  \
+      pc[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.col + k_));                \
+      if (a.val) pv[h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.val + k_));     \
+      else pv[h] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};                                                     \
+    }                                                                                                 \
+  }
+#define FW_CONSUME(CB, BB, EE)                                                                        \
+  _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
+    const unsigned long long k_ = (CB) + (unsigned long long)h * (4 * kFwThreads) + (unsigned long long)tid * 4; \
+    if (k_ < (EE)) {                                                                                  \
+      const uint32_t cc[4] = {pc[h].x, pc[h].y, pc[h].z, pc[h].w};                                    \
+      const float vv[4] = {pv[h].x, pv[h].y, pv[h].z, pv[h].w};                                       \
+      float pr[4];                                                                                    \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
+        const bool ok = (k_ + e >= (BB)) && (k_ + e < (EE));                                          \
+        const uint32_t j = ok ? cc[e] : 0u;                                                           \
+        /* weights beyond the LDS copy are scattered 4-byte reads of a vector that lives in L2 */     \
+        const float wj = j < nhot ? hot[j] : __builtin_nontemporal_load(wsum + j);                    \
+        pr[e] = ok ? wj * vv[e] : 0.0f;                                                               \
+      }                                                                                               \
+      *reinterpret_cast<float4 *>(prod + h * (4 * kFwThreads) + tid * 4) = make_float4(pr[0], pr[1], pr[2], pr[3]); \
+    }                                                                                                 \
+  }
+
+  int cur = 0;
+  uint64_t tile = blockIdx.x;
+  if (tile < ntiles) {
     const uint64_t rbase = a.r0 + tile * kFwRows;
     const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
-    if (tid <= nr) rp[tid] = a.rowptr[rbase + tid];
-    __syncthreads();  // also orders the fill of hot[] before its first use
+    if (tid <= nr) rp0[tid] = a.rowptr[rbase + tid];
+    if (dense && tid < kFwRows) mask0[tid] = tid < nr ? a.hmask[rbase + tid] : 0ull;
+  }
+  __syncthreads();  // also orders the fill of hot[] / tab[] before their first use
+  if (tile < ntiles) {
+    const uint64_t rbase = a.r0 + tile * kFwRows;
+    const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
+    const unsigned long long B = rp0[0], E = rp0[nr];
+    FW_ISSUE(B & ~3ull, E)
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    unsigned long long *rp = rp0 + cur * (kFwRows + 2), *rpn = rp0 + (cur ^ 1) * (kFwRows + 2);
+    unsigned long long *mask_s = mask0 + cur * kFwRows, *maskn = mask0 + (cur ^ 1) * kFwRows;
+    const uint64_t rbase = a.r0 + tile * kFwRows;
+    const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
     const unsigned long long B = rp[0], E = rp[nr];
     const unsigned long long myb = trow < nr ? rp[trow] : E, mye = trow < nr ? rp[trow + 1] : E;
+    // row pointers and masks of the next tile, fetched before this tile's stream is waited for
+    const uint64_t next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
+    const uint64_t rbase_n = a.r0 + next * kFwRows;
+    const int nrn = has_next ? (int)((a.r1 - rbase_n) < (uint64_t)kFwRows ? (a.r1 - rbase_n) : (uint64_t)kFwRows) : 0;
+    unsigned long long rp_next = 0, mk_next = 0;
+    if (has_next) {
+      if (tid <= nrn) rp_next = a.rowptr[rbase_n + tid];
+      if (dense && tid < nrn) mk_next = a.hmask[rbase_n + tid];
+    }
     float rowsum = 0.0f;
-    for (unsigned long long cb = B & ~3ull; cb < E; cb += kFwChunk) {
-#pragma unroll
-      for (int h = 0; h < kFwChunk / (4 * kFwThreads); ++h) {
-        const unsigned long long k = cb + (unsigned long long)h * (4 * kFwThreads) + (unsigned long long)tid * 4;
-        if (k < E) {
-          // the matrix is read once per sweep: non-temporal loads keep it from evicting the
-          // gathered vector from L2
-          const u32x4 c4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.col + k));
-          f32x4 v4 = {1.0f, 1.0f, 1.0f, 1.0f};
-          if (a.val) v4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.val + k));
-          const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
-          const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-          float pr[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool ok = (k + e >= B) && (k + e < E);
-            const uint32_t j = ok ? cc[e] : 0u;
-            float wj;
-            if (a.ablate & 1) wj = __int_as_float(0x3f800000u | (j & 0xFFu));
-            else if (j < nhot) wj = hot[j];
-            else wj = wsum[j];
-            pr[e] = ok ? wj * vv[e] : 0.0f;
-          }
-          *reinterpret_cast<float4 *>(prod + h * (4 * kFwThreads) + tid * 4) = make_float4(pr[0], pr[1], pr[2], pr[3]);
-        }
-      }
-      __syncthreads();
+    unsigned long long cb = B & ~3ull;
+    FW_CONSUME(cb, B, E)
+    if (has_next) {
+      if (tid <= nrn) rpn[tid] = rp_next;
+      if (dense && tid < kFwRows) maskn[tid] = mk_next;
+    }
+    __syncthreads();  // products of the first chunk and the next tile's row pointers are in LDS
+    const bool multi = E > cb + kFwChunk;  // rows so long that the tile needs more passes
+    if (!multi && has_next) {
+      const unsigned long long Bn = rpn[0], En = rpn[nrn];
+      FW_ISSUE(Bn & ~3ull, En)
+    }
+    {
       const unsigned long long s = myb > cb ? myb : cb;
       const unsigned long long e = mye < cb + kFwChunk ? mye : cb + kFwChunk;
-      if (!(a.ablate & 2))
+      for (unsigned long long k = s + q; k < e; k += kFwLanesPerRow) rowsum += prod[k - cb];
+    }
+    if (multi) {
+      for (cb += kFwChunk; cb < E; cb += kFwChunk) {
+        __syncthreads();
+        FW_ISSUE(cb, E)
+        FW_CONSUME(cb, B, E)
+        __syncthreads();
+        const unsigned long long s = myb > cb ? myb : cb;
+        const unsigned long long e = mye < cb + kFwChunk ? mye : cb + kFwChunk;
         for (unsigned long long k = s + q; k < e; k += kFwLanesPerRow) rowsum += prod[k - cb];
-      else if (s < e) rowsum += prod[s - cb];
-      __syncthreads();
+      }
+      if (has_next) {
+        const unsigned long long Bn = rpn[0], En = rpn[nrn];
+        FW_ISSUE(Bn & ~3ull, En)
+      }
+    }
+    if (dense && trow < nr) {
+      const unsigned long long m = mask_s[trow];
+      rowsum += tab[(2 * q) * 256 + (int)((m >> (16 * q)) & 255)] +
+                tab[(2 * q + 1) * 256 + (int)((m >> (16 * q + 8)) & 255)];
     }
 #pragma unroll
     for (int off = 1; off < kFwLanesPerRow; off <<= 1) rowsum += __shfl_xor(rowsum, off, 64);
@@ -132,6 +221,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         const float loss = log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f));
         const float res = 1.0f / (1.0f + expf(-m)) - t;
         a.out[myrow] = res;
+        if (dense) rfx_s[trow] = (unsigned long long)(long long)(res * a.scale);
         acc0 += (double)loss;
         acc1 += (double)res;
       } else {
@@ -140,11 +230,59 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         const int y = lab > 0 ? 1 : 0;
         const float g = p - y;
         a.out[myrow] = g;
+        if (dense) {
+          rfx_s[trow] = (unsigned long long)(long long)(g * a.scale);
+          rfx2_s[trow] = (unsigned long long)(long long)(g * g * a.scale);
+        }
         acc0 += (double)g;
         acc1 += (double)(g * g);
       }
     }
-    __syncthreads();  // rp is rewritten by the next tile
+    __syncthreads();  // the residuals of the tile are in LDS; prod may be overwritten
+    if (dense && MODE != FWD_EVAL) {
+      // X^T r restricted to the mask columns: every wave takes 16 rows of the tile, lane k adds
+      // the rows whose mask has bit k
+      constexpr int kRowsPerWave = kFwRows / (kFwThreads / 64);
+#pragma unroll 4
+      for (int i = 0; i < kRowsPerWave; ++i) {
+        const int rr = wave * kRowsPerWave + i;
+        const unsigned long long m = rr < nr ? mask_s[rr] : 0ull;
+        const bool on = (m >> lane) & 1ull;
+        h1 += on ? rfx_s[rr] : 0ull;
+        if (MODE == FWD_FTRL) h2 += on ? rfx2_s[rr] : 0ull;
+        hseen |= m;
+      }
+      __syncthreads();  // masks / residuals are rewritten during the next tile
+    }
+    cur ^= 1;
+  }
+#undef FW_ISSUE
+#undef FW_CONSUME
+  if (dense && MODE != FWD_EVAL) {
+    // combine the waves' column sums and add them to the global accumulators
+    for (int pass = 0; pass < (MODE == FWD_FTRL ? 2 : 1); ++pass) {
+      __syncthreads();
+      hsum[wave][lane] = pass == 0 ? h1 : h2;
+      __syncthreads();
+      if (tid < 64) {
+        unsigned long long t = 0;
+        for (int i = 0; i < kFwThreads / 64; ++i) t += hsum[i][tid];
+        if (t) atomicAdd((pass == 0 ? a.g1 : a.g2) + a.perm[tid], t);
+      }
+    }
+    if (MODE == FWD_FTRL) {
+      __syncthreads();
+      hsum[wave][lane] = hseen;  // wave-uniform
+      __syncthreads();
+      if (tid < 64) {
+        unsigned long long seen = 0;
+        for (int i = 0; i < kFwThreads / 64; ++i) seen |= hsum[i][0];
+        if ((seen >> tid) & 1ull) {
+          const uint32_t o = a.perm[tid];
+          atomicOr(&a.gmask[o >> 5], 1u << (o & 31));
+        }
+      }
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     acc0 += __shfl_down(acc0, off, 64);
@@ -198,10 +336,21 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
     ADMM_HIP_CHECK(hipGetLastError());
   }
   FwdArgs a{};
-  a.rowptr = csr->d_rowptr;
-  a.col = csr->d_col;
-  a.val = csr->d_val;
+  a.rowptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
+  a.col = csr->hot_dense ? csr->d_ccol : csr->d_col;
+  a.val = csr->hot_dense ? csr->d_cval : csr->d_val;
   a.label = csr->d_label;
+  if (csr->hot_dense) {
+    a.hmask = csr->d_hmask;
+    a.perm = csr->d_perm;
+    if (mode != FWD_EVAL) {
+      ADMM_REQUIRE(csr->has_t, "forward sweep: the training forms need admm_csr_build_transposed");
+      a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
+      a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
+      a.gmask = csr->d_mask;
+      a.scale = std::ldexp(1.0f, csr->fx_shift);
+    }
+  }
   a.r0 = r0;
   a.r1 = r1;
   a.w[0] = csr->d_wsum;
@@ -210,7 +359,6 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.partials = ctx->d_partials;
   a.mode = (int)mode;
   a.nhot = (uint32_t)std::min<uint64_t>(kFwHot, csr->dim);
-  if (const char *ab = getenv("ADMM_ABLATE")) a.ablate = atoi(ab) & 0xFF;
   static bool raised = false;
   if (!raised) {
     for (const void *fn : {reinterpret_cast<const void *>(&k_forward<FWD_EVAL>),
@@ -501,7 +649,7 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
   {
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
-                       ydual, rho, ctx->d_scalars, csr->has_bias ? 1 : 0, g_out, csr->dim, ctx->d_partials);
+                       ydual, rho, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, g_out, csr->dim, ctx->d_partials);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
@@ -621,7 +769,7 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
     {
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
       hipLaunchKernelGGL(k_ftrl_apply, dim3(egrid), dim3(256), 0, ctx->stream, csr->d_g1, csr->d_g2,
-                         std::ldexp(1.0, -csr->fx_shift), csr->d_mask, wcur, w, z, n, alpha, ctx->d_scalars, csr->has_bias ? 1 : 0, csr->dim);
+                         std::ldexp(1.0, -csr->fx_shift), csr->d_mask, wcur, w, z, n, alpha, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, csr->dim);
       ADMM_HIP_CHECK(hipGetLastError());
       const uint64_t words = ((uint64_t)csr->nblocks * csr->col_block) / 32 + 1;
       hipLaunchKernelGGL(k_clear_mask, dim3(grid_for(words, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream,

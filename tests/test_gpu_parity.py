@@ -367,3 +367,32 @@ def test_gradient_is_reproducible(ctx):
     assert f1 == f2
     np.testing.assert_array_equal(g1, g.download())
     dev.destroy()
+
+
+@pytest.mark.parametrize("relabel", [False, True])
+def test_rows_longer_than_a_staging_pass(ctx, oracle, relabel):
+    """tiles whose rows hold more entries than one LDS staging pass (and one row longer than a pass)"""
+    from oracle import oracle as orc
+    dim = 60000
+    rng = np.random.default_rng(77)
+    lens = rng.integers(300, 1500, 400)
+    lens[17] = 20000
+    lens[255] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    col = np.concatenate([np.sort(rng.choice(dim - 1, l, replace=False)) for l in lens]).astype(np.uint32)
+    val = np.where(rng.random(col.shape[0]) < 0.7, 1.0, rng.uniform(0.5, 1.5, col.shape[0])).astype(np.float32)
+    label = (rng.random(400) < 0.5).astype(np.float32)
+    raw = orc.Csr(rowptr, col, val, label, dim)
+    tr = oracle.translate(raw)
+    dev = upload(ctx, raw, dim).build_transposed(panel_rows=128, col_block=4096)
+    if relabel:
+        dev.relabel_by_frequency()
+    x = rng.normal(0, 0.02, dim).astype(np.float32)
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, None, None, None, 0.2)
+    g = ctx.vec(dim)
+    f = dev.logistic_fg(ctx.vec(dim, x), g, rho=0.2)
+    close(f, f_ref)
+    close(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
+    s64, p_ref = oracle.logloss_sum_f64(tr, [x], want_p=True)
+    close(dev.predict([ctx.vec(dim, x)]), p_ref, atol=1e-6)
+    dev.destroy()
