@@ -648,8 +648,8 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   ADMM_REQUIRE(csr, "admm_csr_build_transposed: csr is NULL");
   admm_ctx *ctx = csr->ctx;
   if (col_block == 0) col_block = 8192;
-  ADMM_REQUIRE(col_block <= 8192 && col_block >= 64 && (col_block % 64) == 0,
-               "admm_csr_build_transposed: col_block must be a multiple of 64 in [64, 8192]");
+  ADMM_REQUIRE(col_block <= 16384 && col_block >= 64 && (col_block % 64) == 0,
+               "admm_csr_build_transposed: col_block must be a multiple of 64 in [64, 16384]");
   if (panel_rows == 0) {
     // about a million rows per panel, and a multiple of 8 panels when the set is large enough:
     // the sweep hands each of the 8 XCDs its own panels

@@ -399,7 +399,6 @@ struct TArgs {
   int ablate;                // development switches, 0 in normal operation
 };
 
-constexpr int kTThreads = 512;
 
 typedef unsigned long long fx_t;  // two's-complement fixed point held in an unsigned word
 
@@ -425,7 +424,7 @@ __device__ inline void t_accumulate(fx_t *acc, fx_t *acc2, uint32_t *bits, uint3
 // Workgroups whose index is equal modulo 8 share an XCD under round-robin dispatch; they are
 // given cells of the same panel so that the panel's slice of the per-row vector stays in that
 // XCD's L2 (placement affects speed only).
-template <bool FTRL>
+template <bool FTRL, int kTThreads>
 __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
   extern __shared__ fx_t acc[];  // [CB] (+ [CB] + [CB/32] bitmap in FTRL mode)
   const uint64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -549,17 +548,14 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
   if (const char *ab = getenv("ADMM_ABLATE")) a.ablate = (atoi(ab) >> 8) & 0xFF;
   const size_t lds = ftrl_mode ? sizeof(fx_t) * 2 * csr->col_block + sizeof(uint32_t) * (csr->col_block / 32)
                                : sizeof(fx_t) * csr->col_block;
-  if (lds > 64 * 1024) {
-    static bool raised[2] = {false, false};
-    if (!raised[ftrl_mode]) {
-      if (ftrl_mode)
-        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_transposed<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      else
-        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_transposed<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      raised[ftrl_mode] = true;
-    }
+  // more than half of the CU's LDS: one workgroup per CU, so give it the full 1024 threads
+  const bool big = lds > 72 * 1024;
+  static bool raised = false;
+  if (!raised) {
+    for (const void *fn : {reinterpret_cast<const void *>(&k_transposed<true, 1024>),
+                           reinterpret_cast<const void *>(&k_transposed<false, 1024>)})
+      ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    raised = true;
   }
   KernelTimer t(ctx, ADMM_K_TRANSPOSED);
   // keep each launch's grid below 2^30 workgroups
@@ -569,10 +565,14 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
     a.npanels = std::min<uint64_t>(max_panels, p1 - q0);
     const uint64_t groups = (a.npanels + 7) / 8;
     const uint32_t grid = (uint32_t)(groups * 8 * csr->nblocks);
-    if (ftrl_mode)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<true>), dim3(grid), dim3(kTThreads), lds, ctx->stream, a);
+    if (ftrl_mode && big)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<true, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, a);
+    else if (ftrl_mode)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<true, 512>), dim3(grid), dim3(512), lds, ctx->stream, a);
+    else if (big)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<false, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, a);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<false>), dim3(grid), dim3(kTThreads), lds, ctx->stream, a);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<false, 512>), dim3(grid), dim3(512), lds, ctx->stream, a);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   return ADMM_OK;
@@ -736,6 +736,7 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
                       float alpha, float beta, float l1, float l2, uint64_t batch) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(csr->has_t, "admm_ftrl_pass: batch > 1 needs admm_csr_build_transposed");
+  ADMM_REQUIRE(csr->col_block <= 8192, "admm_ftrl_pass: batch > 1 needs col_block <= 8192 (two accumulators per column)");
   ADMM_REQUIRE(csr->panel_rows == batch || (csr->npanels <= 1 && batch >= csr->nrows),
                "admm_ftrl_pass: batch (%llu) must equal the transposed copy's panel_rows (%llu)",
                (unsigned long long)batch, (unsigned long long)csr->panel_rows);

@@ -60,7 +60,7 @@ void Worker::BaseUpdate(SampleSet &, SampleSet &test_set, const AdmmConfig &admm
       parts_.emplace_back(new SampleSet);
       ADMM_CHECK(parts_.back()->Initialize(train_name, part, num_part_, admm_params.dim));
       if (admm_params.local_solver == "lbfgs")
-        parts_.back()->PrepareTransposed(0, 0, true);
+        parts_.back()->PrepareTransposed(0, 16384, true);
       else if (admm_params.ftrl_batch > 1)
         parts_.back()->PrepareTransposed(admm_params.ftrl_batch, 0, true);
     }

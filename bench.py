@@ -40,7 +40,7 @@ def parse_args():
                     help="feature draws per row; ~99 stay after de-duplication at 2^22 features, +1 bias")
     ap.add_argument("--lbfgs-iters", type=int, default=3)
     ap.add_argument("--panel-rows", type=int, default=0)
-    ap.add_argument("--col-block", type=int, default=8192)
+    ap.add_argument("--col-block", type=int, default=16384)
     ap.add_argument("--test-frac", type=float, default=0.01)
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +184,7 @@ def main():
             pmc = json.load(open(tfile))
             wl = pmc.get("workload", {})
             if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus")) == (rows_total, args.dim, world):
-                sym = "k_transposed<false>" if dom == "transposed_block_sweep" else "k_forward<1>"
+                sym = "k_transposed<false" if dom == "transposed_block_sweep" else "k_forward<1>"
                 for name, rec in pmc["kernels"].items():
                     if sym in name:
                         traffic, traffic_src = rec["traffic_bytes"], "profiles/pmc_traffic_c3.json"
@@ -209,6 +209,7 @@ def main():
                 "objective_gradient_evals_total": evals_total,
                 "admm_iterations_per_s": args.steps / dt,
                 "generate_and_build_s": t_gen,
+                "rank0_hbm_bytes": dict(zip(("row_major", "column_block_copy"), train.bytes())),
                 "last_line": driver.format_line("rank0", *last_rec["line"]) if last_rec and last_rec["line"] else None,
                 "last_residuals": [last_rec["r2"], last_rec["s2"]] if last_rec else None,
             },

@@ -104,8 +104,9 @@ int admm_csr_shape(const admm_csr *csr, uint64_t *nrows, uint64_t *nnz, uint64_t
 int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, float *val,
                       float *label);
 /* Build the column-block copy that the transposed sweep reads (X^T r, mini-batch FTRL):
- * rows are cut into panels of `panel_rows`, columns into blocks of `col_block` (<= 8192),
- * and each (panel, block) cell stores its entries contiguously.  0 picks defaults. */
+ * rows are cut into panels of `panel_rows`, columns into blocks of `col_block` (a multiple of 64,
+ * <= 16384; the mini-batch FTRL pass needs <= 8192), and each (panel, block) cell stores its
+ * entries contiguously.  0 picks defaults (about a million rows, 8192 columns). */
 int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block);
 /* Renumber the stored column ids by decreasing frequency inside this sample set (an internal
  * layout change that speeds up the forward sweep on power-law data: the gathers of frequent

@@ -12,7 +12,7 @@ ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--dim", type=int, default=1 << 22)
 ap.add_argument("--draws", type=float, default=131)
 ap.add_argument("--panel-rows", type=int, default=0)
-ap.add_argument("--col-block", type=int, default=8192)
+ap.add_argument("--col-block", type=int, default=16384)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ablate", type=str, default="0")
 ap.add_argument("--no-relabel", action="store_true")
