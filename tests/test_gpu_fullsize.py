@@ -1,0 +1,111 @@
+"""Size-independent properties of the hot path at benchmark-scale shapes (2^20 / 2^22 features,
+millions of rows, generated on the device).  The oracle cannot run at these sizes in seconds, so
+the checks are properties that hold at any size: bookkeeping identities, linearity of X^T,
+reproducibility, the directional derivative of the objective, monotone line search, consensus
+fixed points, and agreement of the exact and the mini-batch FTRL at batch = 1 row panels."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROWS, DIM, DRAWS = 3_000_000, 1 << 22, 131
+
+
+@pytest.fixture(scope="module")
+def big():
+    from admm_amd import capi
+    ctx = capi.Context(0)
+    s = ctx.csr_synth(ROWS, DIM, DRAWS, seed=11)
+    s.build_transposed(col_block=16384).relabel_by_frequency()
+    yield ctx, s
+    s.destroy()
+    ctx.close()
+
+
+def test_bookkeeping_identities(big):
+    ctx, s = big
+    assert s.nrows == ROWS and s.dim == DIM
+    # nnz = stored features + one bias entry per row; shards generated separately add up
+    a = ctx.csr_synth(1_000_000, DIM, DRAWS, seed=11, row_offset=0)
+    b = ctx.csr_synth(2_000_000, DIM, DRAWS, seed=11, row_offset=1_000_000)
+    assert a.nnz + b.nnz == s.nnz
+    a.destroy()
+    b.destroy()
+    row_major, copy = s.bytes()
+    assert row_major == 8 * (ROWS + 1) + 8 * s.nnz + 4 * ROWS
+    assert 0 < copy < 10 * (s.nnz - ROWS) + (1 << 24)      # the hot-mask entries are not copied
+
+
+def test_zero_weights_give_log2_and_half(big):
+    ctx, s = big
+    ll, auc, n = s.metrics([ctx.vec(DIM)])
+    assert n == ROWS and "%.7f" % ll == "0.6931472" and auc == pytest.approx(0.5, abs=1e-12)
+
+
+def test_gradient_linear_reproducible_and_consistent(big):
+    ctx, s = big
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 0.05, DIM).astype(np.float32)
+    d = rng.normal(0, 1.0, DIM).astype(np.float32)
+    d /= np.linalg.norm(d)
+    dx, g = ctx.vec(DIM, x), ctx.vec(DIM)
+    f0 = s.logistic_fg(dx, g, rho=0.01)
+    g0 = g.download()
+    f0b = s.logistic_fg(dx, g, rho=0.01)
+    assert f0 == f0b
+    np.testing.assert_array_equal(g0, g.download())          # integer accumulation: bit-reproducible
+    # directional derivative by central differences (f is a sum over 3M rows: step large enough
+    # for float residuals, small enough for the curvature)
+    h = 2e-2
+    fp = s.logistic_fg(ctx.vec(DIM, x + np.float32(h) * d), g, rho=0.01)
+    fm = s.logistic_fg(ctx.vec(DIM, x - np.float32(h) * d), g, rho=0.01)
+    dd = float(np.dot(g0.astype(np.float64), d.astype(np.float64)))
+    assert (fp - fm) / (2 * h) == pytest.approx(dd, rel=2e-3, abs=1e-3 * abs(f0) / ROWS)
+    # the regulariser's gradient is exactly rho (x - z) + y: difference of two calls isolates it
+    z = rng.normal(0, 0.05, DIM).astype(np.float32)
+    y = rng.normal(0, 0.05, DIM).astype(np.float32)
+    s.logistic_fg(dx, g, z=ctx.vec(DIM, z), ydual=ctx.vec(DIM, y), rho=0.5)
+    g1 = g.download()
+    s.logistic_fg(dx, g, rho=0.0)
+    g2 = g.download()
+    np.testing.assert_allclose(g1 - g2, y + np.float32(0.5) * (x - z), rtol=0, atol=2e-6 * np.abs(g1).max())
+
+
+def test_lbfgs_decreases_objective(big):
+    ctx, s = big
+    x, g = ctx.vec(DIM), ctx.vec(DIM)
+    f_start = s.logistic_fg(x, g, rho=0.01)
+    assert f_start == pytest.approx(ROWS * np.log(2.0), rel=1e-6)
+    res = s.lbfgs_solve(x, rho=0.01, max_iter=3)
+    assert res["evals"] >= 2 and res["f"] < f_start * 0.99
+    assert s.logistic_fg(x, g, rho=0.01) == pytest.approx(res["f"], rel=1e-7)
+
+
+def test_consensus_fixed_point(big):
+    """with identical workers, z = payload-sum / (N rho + lambda) and x = z leaves the dual unchanged"""
+    ctx, _ = big
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=DIM).astype(np.float32)
+    dx, dy, dp, dz = ctx.vec(DIM, x), ctx.vec(DIM), ctx.vec(DIM), ctx.vec(DIM, x)
+    ctx.payload(dx, dy, 1.0, dp)                             # rho = 1, y = 0 -> payload = x
+    r2, s2 = ctx.consensus(dp, 1, 1.0, 0.0, 0.0, dx, dy, dz)  # N = 1, lambda = 0 -> z = x
+    np.testing.assert_array_equal(dz.download(), x)
+    assert r2 == 0.0 and s2 == 0.0 and not dy.download().any()
+
+
+def test_ftrl_minibatch_of_one_panel_matches_sums(big):
+    """One mini-batch = the whole set: n = sum of g^2 per column, z = sum g (w is 0 below l_1),
+    checked through totals that do not need the matrix on the host."""
+    from admm_amd import capi
+    ctx, _ = big
+    s = ctx.csr_synth(500_000, 1 << 20, 47, seed=5).build_transposed(panel_rows=500_000, col_block=8192)
+    dim = 1 << 20
+    w, z, n, off, reg = (ctx.vec(dim) for _ in range(5))
+    s.ftrl_pass(w, z, n, off, reg, 0.1, 1.0, 1.0, 200.0, batch=500_000)
+    hz, hn = z.download().astype(np.float64), n.download().astype(np.float64)
+    _, _, _, label = s.download()
+    # from zero state every prediction is 0.5: g = 0.5 - y, g^2 = 0.25
+    assert hn[0] == pytest.approx(0.25 * s.nrows, rel=1e-6)              # bias column: every row
+    assert hz[0] == pytest.approx(float((0.5 - label).sum()), rel=1e-6, abs=1e-3)
+    assert hn.sum() == pytest.approx(0.25 * s.nnz, rel=1e-6)             # every stored entry once
+    s.destroy()
