@@ -4,6 +4,9 @@
 // wavefront; the parallelism is across the coordinates of a row (one lane each).
 #include "internal.h"
 
+#include <algorithm>
+#include <type_traits>
+
 using namespace admm_impl;
 
 namespace admm_impl {
@@ -33,6 +36,22 @@ __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// Sum over the wavefront with DPP adds (no LDS round trips); every lane returns the total.
+__device__ inline float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                           decltype(row_mask)::value, 0xF, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x124>{}, std::integral_constant<int, 0xF>{});  // row_ror:4
+  v += dpp(v, std::integral_constant<int, 0x128>{}, std::integral_constant<int, 0xF>{});  // row_ror:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast:15
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast:31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ inline float seq_sigmoid(float margin) {
@@ -184,6 +203,195 @@ __global__ void __launch_bounds__(64) k_ftrl_seq(SeqArgs a) {
   }
 }
 
+// ---- pipelined exact pass ---------------------------------------------------------------------
+//
+// The dependence between rows goes through the coordinates they share.  Which earlier row last
+// touched each stored coordinate, and at which position, depends only on the data, so it is
+// computed once per sample set (d_dep).  With that, one wavefront can run several rows ahead:
+// the state of row t+kAhead is gathered from memory while row t is being solved, and every
+// coordinate that one of the last kRing-1 rows has updated since takes its value from a small
+// LDS ring of those rows' results instead of the (possibly stale) gathered value.  Rows older
+// than the ring were stored at least kRing - kAhead rows before the gather was issued.
+constexpr int kRing = 8;       // rows whose results stay in LDS
+constexpr int kAhead = 4;      // state gathers are issued this many rows ahead
+constexpr int kStatic = 8;     // column ids / values / dependences are fetched this many rows ahead
+
+// Every load below is unconditional (indices are clamped, results masked), and the pipeline is
+// filled by running the same loop body over kStatic empty rows in front of row 0: a load under a
+// branch, or a separate prologue, would make the number of requests in flight unknown to the
+// compiler at the top of the loop, which then waits for ALL of them and so undoes the look-ahead.
+// EPL = stored entries per lane: rows of up to 64 * EPL entries
+template <int EPL, bool HASVAL>
+__global__ void __launch_bounds__(64)
+    k_ftrl_seq_ring(SeqArgs a, const uint32_t *__restrict__ col, const uint32_t *__restrict__ dep, uint64_t nnz) {
+  __shared__ float ring_z_[kRing][64 * EPL];
+  __shared__ float ring_n_[kRing][64 * EPL];
+  // plain (not volatile) LDS accesses: a wavefront's LDS operations execute in order, and a
+  // volatile access would make the compiler drain every outstanding load around it
+  float(*ring_z)[64 * EPL] = ring_z_;
+  float(*ring_n)[64 * EPL] = ring_n_;
+  const int lane = threadIdx.x;
+  float *w = a.w, *z = a.z, *n = a.n;
+  const long long nrows = (long long)a.nrows;
+  const long long total = nrows + 1;  // + the trailing Predict on the last row
+  const uint64_t last_entry = nnz - 1;
+  // static per-row data, kStatic rows deep
+  uint32_t s_col[kStatic][EPL], s_dep[kStatic][EPL];
+  float s_val[kStatic][EPL];
+  uint32_t s_len[kStatic];
+  float s_lab[kStatic];
+  // gathered state, kAhead rows deep
+  float g_z[kAhead][EPL], g_n[kAhead][EPL], g_r[kAhead][EPL], g_o[kAhead][EPL];
+#pragma unroll
+  for (int u = 0; u < kStatic; ++u) {
+    s_len[u] = 0;
+    s_lab[u] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s_col[u][e] = 0, s_dep[u][e] = 0, s_val[u][e] = 0.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) g_z[u][e] = g_n[u][e] = g_r[u][e] = g_o[u][e] = 0.0f;
+  // Row pointers and labels travel one group of kStatic rows per lane set: lane u of a group's
+  // registers holds row (group * kStatic + u).  `nx` is the group whose static data is fetched
+  // during the current group, `nn` the one after it (still in flight).
+  unsigned long long nx_lo, nx_hi, nn_lo, nn_hi;
+  float nx_lab, nn_lab;
+  auto load_group = [&](long long grp, unsigned long long &lo, unsigned long long &hi, float &lab) {
+    long long r = grp * kStatic + (lane & (kStatic - 1));
+    r = r < 0 ? 0 : (r < nrows ? r : nrows - 1);  // the trailing Predict re-reads the last row
+    lo = a.rowptr[r];
+    hi = a.rowptr[r + 1];
+    lab = a.label[r];
+  };
+  load_group(0, nx_lo, nx_hi, nx_lab);
+  load_group(1, nn_lo, nn_hi, nn_lab);
+  const long long ngroups = (total + kStatic - 1) / kStatic;
+  for (long long grp = -1; grp < ngroups; ++grp) {
+#pragma unroll
+    for (int u = 0; u < kStatic; ++u) {
+      const long long t = grp * kStatic + u;  // rows before 0 and past the end have length 0
+      const bool tail = t == nrows;
+      const uint32_t len = s_len[u];
+      float sw = 0.0f, so = 0.0f;
+      float zj[EPL], nj[EPL], wj[EPL];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const uint32_t k = lane + 64 * e;
+        const uint32_t d = tail ? ((1u << 16) | k) : s_dep[u][e];
+        const uint32_t back = d >> 16, pos = d & 0xFFFFu;
+        const bool fwd = k < len && back >= 1 && back < (uint32_t)kRing;
+        const uint32_t slot = ((uint32_t)u - back) & (kRing - 1);  // kStatic == kRing: t mod kRing == u
+        const float rz = ring_z[slot][fwd ? pos : 0], rn = ring_n[slot][fwd ? pos : 0];
+        zj[e] = fwd ? rz : g_z[u % kAhead][e];
+        nj[e] = fwd ? rn : g_n[u % kAhead][e];
+        wj[e] = seq_weight(zj[e], nj[e], g_r[u % kAhead][e], a.alpha, a.beta, a.l1, a.l2);
+        if (k < len) w[s_col[u][e]] = wj[e];
+        sw += k < len ? wj[e] * s_val[u][e] : 0.0f;
+        so += k < len ? g_o[u % kAhead][e] * s_val[u][e] : 0.0f;
+      }
+      const float p = seq_sigmoid(wave_sum_dpp(sw) + wave_sum_dpp(so));
+      const int y = s_lab[u] > 0 ? 1 : 0;
+      const float g = p - y;
+      const float g2 = g * g;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const uint32_t k = lane + 64 * e;
+        const double sigma = (sqrt((double)(nj[e] + g2)) - sqrt((double)nj[e])) / (double)a.alpha;
+        const float zn = (float)((double)zj[e] + ((double)g - sigma * (double)wj[e]));
+        const float nn = nj[e] + g2;
+        if (k < len && !tail) {
+          const uint32_t j = s_col[u][e];
+          z[j] = zn;
+          n[j] = nn;
+          ring_z[u][k] = zn;
+          ring_n[u][k] = nn;
+        }
+      }
+      // keep the order: this row's stores, then the gather for row t + kAhead, then the static
+      // fetch for row t + kStatic
+      asm volatile("" ::: "memory");
+      {
+        const int su = (u + kAhead) % kStatic;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const uint32_t j = s_col[su][e];
+          g_z[u % kAhead][e] = z[j];
+          g_n[u % kAhead][e] = n[j];
+          g_r[u % kAhead][e] = a.reg[j];
+          g_o[u % kAhead][e] = a.offset[j];
+        }
+      }
+      {
+        const long long tn = t + kStatic;
+        const unsigned long long b = __shfl(nx_lo, u, 64);
+        const unsigned long long e1 = __shfl(nx_hi, u, 64);
+        s_lab[u] = __shfl(nx_lab, u, 64);
+        s_len[u] = tn < total ? (uint32_t)(e1 - b) : 0u;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const uint32_t k = lane + 64 * e;
+          const bool on = k < s_len[u];
+          const uint64_t at = on ? b + k : last_entry;
+          // raw values; lanes past the row's end are masked where the values are used, so that
+          // nothing here waits for these loads
+          s_col[u][e] = col[at];
+          s_val[u][e] = HASVAL ? a.val[at] : 1.0f;
+          s_dep[u][e] = dep[at];
+        }
+      }
+    }
+    nx_lo = nn_lo;
+    nx_hi = nn_hi;
+    nx_lab = nn_lab;
+    load_group(grp + 3, nn_lo, nn_hi, nn_lab);
+  }
+}
+
+// (rows_back << 16) | position for every stored entry, computed on the host from the device CSR
+static int ensure_dep(admm_csr *csr) {
+  if (csr->d_dep) return ADMM_OK;
+  admm_ctx *ctx = csr->ctx;
+  std::vector<uint64_t> rowptr(csr->nrows + 1);
+  std::vector<uint32_t> col(csr->nnz);
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ADMM_HIP_CHECK(hipMemcpy(rowptr.data(), csr->d_rowptr, sizeof(uint64_t) * (csr->nrows + 1), hipMemcpyDeviceToHost));
+  if (csr->nnz) ADMM_HIP_CHECK(hipMemcpy(col.data(), csr->d_col, sizeof(uint32_t) * csr->nnz, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> dep(csr->nnz);
+  std::vector<int64_t> last_row(csr->dim, -1);
+  std::vector<uint32_t> last_pos(csr->dim, 0);
+  uint64_t max_len = 0;
+  for (uint64_t r = 0; r < csr->nrows; ++r) {
+    const uint64_t b = rowptr[r], e = rowptr[r + 1];
+    max_len = std::max(max_len, e - b);
+    for (uint64_t k = b; k < e; ++k) {
+      const uint32_t c = col[k];
+      uint32_t d = 0;
+      if (last_row[c] >= 0) {
+        const uint64_t back = r - (uint64_t)last_row[c];
+        if (back < 0xFFFF && last_pos[c] < 0x10000u) d = ((uint32_t)back << 16) | last_pos[c];
+      }
+      dep[k] = d;
+      last_row[c] = (int64_t)r;
+      last_pos[c] = (uint32_t)std::min<uint64_t>(k - b, 0xFFFFFFFFull);
+    }
+  }
+  csr->max_row_len = max_len;
+  if (csr->d_perm && csr->nnz) {
+    // relabelled set: the pass addresses the state by original ids; translate once
+    std::vector<uint32_t> perm(csr->dim);
+    ADMM_HIP_CHECK(hipMemcpy(perm.data(), csr->d_perm, sizeof(uint32_t) * csr->dim, hipMemcpyDeviceToHost));
+    for (uint64_t k = 0; k < csr->nnz; ++k) col[k] = perm[col[k]];
+    ADMM_HIP_CHECK(hipMalloc(&csr->d_seqcol, sizeof(uint32_t) * (csr->nnz + 8)));
+    ADMM_HIP_CHECK(hipMemcpy(csr->d_seqcol, col.data(), sizeof(uint32_t) * csr->nnz, hipMemcpyHostToDevice));
+  }
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_dep, sizeof(uint32_t) * (csr->nnz + 8)));
+  if (csr->nnz) ADMM_HIP_CHECK(hipMemcpy(csr->d_dep, dep.data(), sizeof(uint32_t) * csr->nnz, hipMemcpyHostToDevice));
+  return ADMM_OK;
+}
+
 int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,
                          float alpha, float beta, float l1, float l2) {
   admm_ctx *ctx = csr->ctx;
@@ -204,9 +412,18 @@ int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const floa
   a.beta = beta;
   a.l1 = l1;
   a.l2 = l2;
+  if (!csr->has_dup_cols && !getenv("ADMM_FTRL_FENCED")) ADMM_TRY(ensure_dep(csr));
   KernelTimer t(ctx, ADMM_K_FTRL_SEQ);
   if (csr->has_dup_cols)
     hipLaunchKernelGGL(k_ftrl_seq_serial, dim3(1), dim3(64), 0, ctx->stream, a);
+  else if (csr->d_dep && csr->nnz && csr->max_row_len <= 128) {
+    using Kern = void (*)(SeqArgs, const uint32_t *, const uint32_t *, uint64_t);
+    static const Kern table[2][2] = {{k_ftrl_seq_ring<1, false>, k_ftrl_seq_ring<1, true>},
+                                     {k_ftrl_seq_ring<2, false>, k_ftrl_seq_ring<2, true>}};
+    const Kern kern = table[csr->max_row_len > 64][csr->d_val != nullptr];
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, ctx->stream, a, csr->d_seqcol ? csr->d_seqcol : csr->d_col,
+                       csr->d_dep, csr->nnz);
+  }
   else
     hipLaunchKernelGGL(k_ftrl_seq, dim3(1), dim3(64), 0, ctx->stream, a);
   ADMM_HIP_CHECK(hipGetLastError());

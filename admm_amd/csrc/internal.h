@@ -95,6 +95,11 @@ struct admm_csr {
   float *d_cval = nullptr;
   uint64_t cnnz = 0;
   uint32_t fwd_lpr = 16;      // lanes per row of the forward sweep
+  // sequential FTRL pass: per stored entry, how many rows back its column was last stored (0 =
+  // never or more than 65535 rows back) and at which position of that row: (rows_back << 16) | pos
+  uint32_t *d_dep = nullptr;
+  uint32_t *d_seqcol = nullptr;  // relabelled sets: the stored columns as original ids, for that pass
+  uint64_t max_row_len = 0;
   // transposed (column-block) copy
   bool has_t = false;
   uint64_t panel_rows = 0;

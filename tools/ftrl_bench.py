@@ -21,11 +21,14 @@ for b in [int(x) for x in args.batch.split(",")]:
     if b > 1:
         s.build_transposed(panel_rows=b)
     w, z, n, off, reg = (ctx.vec(args.dim) for _ in range(5))
-    ctx.sync()
-    t0 = time.perf_counter()
-    s.ftrl_pass(w, z, n, off, reg, 0.01, 1.0, 0.4, 2.5, batch=b)
-    ctx.sync()
-    dt = time.perf_counter() - t0
+    for rep in range(2):  # the first pass also prepares per-set side data
+        ctx.sync()
+        t0 = time.perf_counter()
+        s.ftrl_pass(w, z, n, off, reg, 0.01, 1.0, 0.4, 2.5, batch=b)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        if rep == 0:
+            print("first pass %.3f s" % dt, flush=True)
     ll, auc, _ = s.metrics([w])
     print("batch %-8d %.3f s  %.3e nnz/s  %.3e rows/s   train logloss %.5f auc %.5f"
           % (b, dt, s.nnz / dt, s.nrows / dt, ll, auc), flush=True)
