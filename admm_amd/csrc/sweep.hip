@@ -27,7 +27,8 @@ struct FwdArgs {
   float *out;
   double *partials;
   int mode;
-  int ablate;  // development switches, 0 in normal operation
+  uint32_t rows_per_tile;  // <= kFwRowSlots
+  uint32_t dim;            // entries of w[0]
   uint32_t nhot;  // leading entries of w[0] cached in LDS
   // compact sets: per-row mask of unit entries in columns 0..63 (nullptr otherwise), and where the
   // per-column sums of those columns go (64-bit fixed point accumulators indexed by original id)
@@ -44,49 +45,73 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline float clamp35(float m) { return fmaxf(fminf(m, 35.0f), -35.0f); }
 
-// Forward sweep geometry: one workgroup of kFwThreads threads owns kFwRows consecutive rows;
-// kFwChunk stored entries are staged per pass; the first kFwHot entries of the gathered vector
-// are cached in LDS.
-constexpr int kFwThreads = 1024;
-constexpr int kFwRows = 256;
-constexpr int kFwChunk = 16384;
+// Forward sweep geometry: one workgroup per CU, split into kFwConsumers reducing threads and
+// kFwProducers streaming threads; a tile is up to kFwRowSlots consecutive rows (the launch picks
+// the count so that a tile's stored entries normally fit one chunk of kFwChunk entries); the
+// first kFwHot entries of the gathered vector are cached in LDS.
+constexpr int kFwConsumers = 256;
+constexpr int kFwProducers = 512;
+constexpr int kFwThreads = kFwConsumers + kFwProducers;
+constexpr int kFwRowSlots = 128;
+constexpr int kFwChunk = 8192;
 constexpr int kFwHot = 16384;
-constexpr int kFwLanesPerRow = kFwThreads / kFwRows;  // 4
-constexpr size_t kFwLds = sizeof(float) * (kFwChunk + kFwHot + 8 * 256) +
-                          sizeof(unsigned long long) * (2 * (kFwRows + 2) + 4 * kFwRows) + 64;
+constexpr int kFwLanesPerRow = kFwConsumers / kFwRowSlots;  // 2
+constexpr int kFwSlots = 4;                                  // tiles whose row data is resident in LDS
+constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 2) * kFwRowSlots) +
+                          sizeof(unsigned long long) * (kFwSlots * (kFwRowSlots + 2) + kFwSlots * kFwRowSlots +
+                                                        2 * kFwRowSlots) + 64;
 
 // CSR-stream forward sweep.  The stored entries of a tile's rows are one contiguous range of
-// col/val, which all threads stream with 16-byte loads (four entries per lane per load, several
-// loads in flight), gather the weight of each entry, and park the products in LDS in storage
-// order.  Then four lanes per row add up that row's slice of LDS.  Rows longer than a chunk span
-// several passes.  The sigmoid / loss epilogue runs once per row.
+// col/val.  Producer threads stream it with 16-byte loads (four entries per lane per load),
+// gather the weight of each entry, and park the products in LDS in storage order; consumer
+// threads (two lanes per row) add up each row's slice of LDS, run the sigmoid / loss epilogue
+// once per row, and accumulate X^T r of the mask columns.
 //
-// The gather is what bounds this kernel: a wave-wide gather of 64 scattered floats costs the
-// vector memory pipe about one clock per lane.  The sample set's columns are therefore relabelled
-// by decreasing frequency (power-law data: a few thousand columns hold most entries), the
-// gathered vector `wsum` is stored in that order, and its first kFwHot entries are kept in LDS,
-// where a gather is an order of magnitude cheaper.
+// The gather is what bounds this kernel: a wave-wide gather of scattered floats costs the vector
+// memory pipe 2 clocks per active lane when it hits L2 (6.6 when it does not), and only when
+// enough of them are in flight.  The sample set's columns are therefore relabelled by decreasing
+// frequency (power-law data: a few thousand columns hold most entries), the gathered vector
+// `wsum` is stored in that order, and its first kFwHot entries are kept in LDS, where a gather is
+// an order of magnitude cheaper.
+//
+// A wave that issues loads stalls until the memory pipe has accepted them, so the waves that
+// feed the pipe do nothing else: while the consumers reduce tile i (product buffer half i & 1),
+// the producers issue the stream of tile i+2 and, behind it, the gathers of tile i+1, wait, and
+// write the products of tile i+1 to the other half.  Both roles meet at the same barriers.
+// The gathers are exec-masked loads written as inline assembly with one explicit wait: at the
+// first use of a load issued under a branch the compiler would wait for ALL outstanding loads
+// after every single gather, and an unconditional gather costs the pipe a clock per lane even
+// for lanes that fetch nothing.
 template <int MODE>
 __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   extern __shared__ unsigned long long fw_lds[];
-  unsigned long long *rp0 = fw_lds;                                     // [2][kFwRows + 2] row pointers
-  unsigned long long *mask0 = rp0 + 2 * (kFwRows + 2);                  // [2][kFwRows] hot masks
-  unsigned long long *rfx_s = mask0 + 2 * kFwRows;                      // [kFwRows] residual, fixed point
-  unsigned long long *rfx2_s = rfx_s + kFwRows;                         // [kFwRows] its square (FTRL form)
-  float *prod = reinterpret_cast<float *>(rfx2_s + kFwRows);            // [kFwChunk]
-  float *hot = prod + kFwChunk;                                         // [kFwHot]
+  unsigned long long *rp0 = fw_lds;                                     // [kFwSlots][kFwRowSlots + 2] row pointers
+  unsigned long long *mask0 = rp0 + kFwSlots * (kFwRowSlots + 2);       // [kFwSlots][kFwRowSlots] hot masks
+  unsigned long long *rfx_s = mask0 + kFwSlots * kFwRowSlots;           // [kFwRowSlots] residual, fixed point
+  unsigned long long *rfx2_s = rfx_s + kFwRowSlots;                     // [kFwRowSlots] its square (FTRL form)
+  float *prod0 = reinterpret_cast<float *>(rfx2_s + kFwRowSlots);       // [2][kFwChunk]
+  float *hot = prod0 + 2 * kFwChunk;                                    // [kFwHot]
   float *tab = hot + kFwHot;                                            // [8][256] byte -> sum of hot weights
+  float *lab0 = tab + 8 * 256;                                          // [kFwSlots][kFwRowSlots] labels
+  float *msum = lab0 + kFwSlots * kFwRowSlots;                          // [kFwRowSlots] margins of the tile
+  float *out_s = msum + kFwRowSlots;                                    // [kFwRowSlots] per-row results of the tile
   __shared__ double shred[kFwThreads / 64];
-  __shared__ unsigned long long hsum[kFwThreads / 64][64];
-  constexpr int H = kFwChunk / (4 * kFwThreads);  // 16-byte loads per thread and chunk
+  // after the tile loop the product buffer is free: per-wave column sums are combined there
+  unsigned long long(*hsum)[64] = reinterpret_cast<unsigned long long(*)[64]>(prod0);
+  constexpr int H = kFwChunk / (4 * kFwProducers);  // 16-byte loads per producer thread and chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int trow = tid / kFwLanesPerRow, q = tid % kFwLanesPerRow;
+  const bool producer = tid >= kFwConsumers;
+  const int ptid = tid - kFwConsumers;  // producers: 0 .. kFwProducers-1
+  const int trow = tid / kFwLanesPerRow, q = tid % kFwLanesPerRow;  // consumers
   const uint64_t nrows = a.r1 - a.r0;
-  const uint64_t ntiles = (nrows + kFwRows - 1) / kFwRows;
+  const uint32_t rpt = a.rows_per_tile;
+  const uint64_t ntiles = (nrows + rpt - 1) / rpt;
   const float *__restrict__ wsum = a.w[0];
   const uint32_t nhot = a.nhot;
   const bool dense = a.hmask != nullptr;
+  const bool hasval = a.val != nullptr;
+  const bool colsums = dense && MODE != FWD_EVAL;  // X^T r of the mask columns is wanted
   for (uint32_t j = tid; j < nhot; j += kFwThreads) hot[j] = wsum[j];
   if (dense) {
     // tab[g][byte] = sum of the weights of columns 8g .. 8g+7 selected by the bits of `byte`
@@ -104,161 +129,286 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   // per-lane sums of the 64 mask columns over the rows this wave has seen (lane k <-> column k)
   unsigned long long h1 = 0, h2 = 0, hseen = 0;
 
-  // streamed entries of one chunk, four per 16-byte load, held in registers between the load and
-  // the gather so that the next tile's stream is in flight while this tile is being finished
-  u32x4 pc[H];
-  f32x4 pv[H];
-#define FW_ISSUE(CB, EE)                                                                              \
-  _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
-    const unsigned long long k_ = (CB) + (unsigned long long)h * (4 * kFwThreads) + (unsigned long long)tid * 4; \
-    if (k_ < (EE)) {                                                                                  \
-      pc[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.col + k_));                \
-      if (a.val) pv[h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.val + k_));     \
-      else pv[h] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};                                                     \
+  // producers: two register sets of streamed entries, X = the tile whose gathers are next,
+  // Y = the one after it; gw = gathered weights
+  u32x4 xc[H], yc[H];
+  f32x4 xv[H], yv[H];
+  float gw[4 * H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    xc[h] = yc[h] = u32x4{0, 0, 0, 0};
+    xv[h] = yv[h] = f32x4{0, 0, 0, 0};
+  }
+  // the gathered vector as a buffer resource (dim * 4 bytes)
+  const uint64_t wbase = reinterpret_cast<uint64_t>(wsum);
+  const u32x4 wres = {(uint32_t)wbase, (uint32_t)(wbase >> 32) & 0xFFFFu, a.dim * 4u, 0x00020000u};
+  // 16-byte groups past the tile's end re-read its last group
+#define FW_ISSUE(PC, PV, CB, EE)                                                                      \
+  {                                                                                                   \
+    const unsigned long long last_ = ((EE) > (CB) ? (EE) - 1 : (CB)) & ~3ull;                         \
+    _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                   \
+      unsigned long long k_ = (CB) + (unsigned long long)h * (4 * kFwProducers) + (unsigned long long)ptid * 4; \
+      k_ = k_ < last_ ? k_ : last_;                                                                   \
+      PC[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.col + k_));                \
+      if (hasval) PV[h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.val + k_));    \
+      else PV[h] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};                                                     \
     }                                                                                                 \
   }
-#define FW_CONSUME(CB, BB, EE)                                                                        \
+  // Gathers of the weights that are not in the LDS copy.  LO / HI are the tile's first and
+  // one-past-last entry as positions inside the chunk; register slots outside [LO, HI) (the chunk
+  // starts 16-byte aligned, and slots past the tile's end hold a repeat of its last group) are
+  // blanked here once -- column 0, value 0 -- so that no later step needs a range check.
+#define FW_GATHER(LO, HI)                                                                             \
   _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
-    const unsigned long long k_ = (CB) + (unsigned long long)h * (4 * kFwThreads) + (unsigned long long)tid * 4; \
-    if (k_ < (EE)) {                                                                                  \
-      const uint32_t cc[4] = {pc[h].x, pc[h].y, pc[h].z, pc[h].w};                                    \
-      const float vv[4] = {pv[h].x, pv[h].y, pv[h].z, pv[h].w};                                       \
+    const uint32_t p_ = (uint32_t)(h * (4 * kFwProducers) + ptid * 4);                                \
+    uint32_t cc[4] = {xc[h].x, xc[h].y, xc[h].z, xc[h].w};                                            \
+    if (p_ < (LO) || p_ + 4 > (HI)) {                                                                 \
+      float vv[4] = {xv[h].x, xv[h].y, xv[h].z, xv[h].w};                                             \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
+        const bool out = p_ + e < (LO) || p_ + e >= (HI);                                             \
+        cc[e] = out ? 0u : cc[e];                                                                     \
+        vv[e] = out ? 0.0f : vv[e];                                                                   \
+      }                                                                                               \
+      xc[h] = u32x4{cc[0], cc[1], cc[2], cc[3]};                                                      \
+      xv[h] = f32x4{vv[0], vv[1], vv[2], vv[3]};                                                      \
+    }                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+      gw[4 * h + e] = 0.0f;                                                                           \
+      const uint32_t off_ = cc[e] << 2;                                                               \
+      if (cc[e] >= nhot)                                                                              \
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(gw[4 * h + e]) : "v"(off_), "s"(wres) : "memory"); \
+    }                                                                                                 \
+  }
+#define FW_PRODUCTS(PROD, HI)                                                                         \
+  _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
+    const uint32_t p_ = (uint32_t)(h * (4 * kFwProducers) + ptid * 4);                                \
+    if (p_ < (HI)) {                                                                                  \
+      const uint32_t cc[4] = {xc[h].x, xc[h].y, xc[h].z, xc[h].w};                                    \
+      const float vv[4] = {xv[h].x, xv[h].y, xv[h].z, xv[h].w};                                       \
       float pr[4];                                                                                    \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
-        const bool ok = (k_ + e >= (BB)) && (k_ + e < (EE));                                          \
-        const uint32_t j = ok ? cc[e] : 0u;                                                           \
-        /* weights beyond the LDS copy are scattered 4-byte reads of a vector that lives in L2 */     \
-        const float wj = j < nhot ? hot[j] : __builtin_nontemporal_load(wsum + j);                    \
-        pr[e] = ok ? wj * vv[e] : 0.0f;                                                               \
+        const float hv = hot[cc[e] < nhot ? cc[e] : 0u]; /* read, then select: no pointer select */  \
+        pr[e] = (cc[e] < nhot ? hv : gw[4 * h + e]) * vv[e];                                          \
       }                                                                                               \
-      *reinterpret_cast<float4 *>(prod + h * (4 * kFwThreads) + tid * 4) = make_float4(pr[0], pr[1], pr[2], pr[3]); \
+      *reinterpret_cast<float4 *>((PROD) + p_) = make_float4(pr[0], pr[1], pr[2], pr[3]);             \
     }                                                                                                 \
   }
+  // a tile's [LO, HI) from its first and one-past-last stored entry
+#define FW_RANGE(BB, EE, LO, HI)                                                                      \
+  const uint32_t LO = (uint32_t)((BB) & 3ull);                                                        \
+  const uint32_t HI = (uint32_t)(((EE) - ((BB) & ~3ull)) < (unsigned long long)kFwChunk ? ((EE) - ((BB) & ~3ull)) : (unsigned long long)kFwChunk);
 
-  int cur = 0;
-  uint64_t tile = blockIdx.x;
-  if (tile < ntiles) {
-    const uint64_t rbase = a.r0 + tile * kFwRows;
-    const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
-    if (tid <= nr) rp0[tid] = a.rowptr[rbase + tid];
-    if (dense && tid < kFwRows) mask0[tid] = tid < nr ? a.hmask[rbase + tid] : 0ull;
+  // this workgroup's tiles: blockIdx.x + i * gridDim.x
+  const uint64_t nmine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  auto tile_of = [&](uint64_t i) { return blockIdx.x + i * (uint64_t)gridDim.x; };
+  auto tile_rows = [&](uint64_t t) {
+    const uint64_t rb = a.r0 + t * rpt;
+    return (int)((a.r1 - rb) < (uint64_t)rpt ? (a.r1 - rb) : (uint64_t)rpt);
+  };
+  // park the row data of the first tiles in their LDS slots
+  for (uint64_t i = 0; i < 3 && i < nmine; ++i) {
+    const int slot = (int)(i % kFwSlots);
+    const uint64_t rb = a.r0 + tile_of(i) * rpt;
+    const int nr = tile_rows(tile_of(i));
+    if (tid <= nr) rp0[slot * (kFwRowSlots + 2) + tid] = a.rowptr[rb + tid];
+    if (tid < kFwRowSlots) {
+      mask0[slot * kFwRowSlots + tid] = (dense && tid < nr) ? a.hmask[rb + tid] : 0ull;
+      lab0[slot * kFwRowSlots + tid] = tid < nr ? a.label[rb + tid] : 0.0f;
+    }
   }
   __syncthreads();  // also orders the fill of hot[] / tab[] before their first use
-  if (tile < ntiles) {
-    const uint64_t rbase = a.r0 + tile * kFwRows;
-    const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
-    const unsigned long long B = rp0[0], E = rp0[nr];
-    FW_ISSUE(B & ~3ull, E)
+  if (producer) {
+    if (nmine > 0) {
+      const unsigned long long B = rp0[0], E = rp0[tile_rows(tile_of(0))];
+      FW_RANGE(B, E, lo0, hi0)
+      FW_ISSUE(xc, xv, B & ~3ull, E)
+      FW_GATHER(lo0, hi0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FW_PRODUCTS(prod0, hi0)
+    }
+    if (nmine > 1) {
+      const unsigned long long *rp = rp0 + 1 * (kFwRowSlots + 2);
+      const unsigned long long B = rp[0], E = rp[tile_rows(tile_of(1))];
+      FW_ISSUE(xc, xv, B & ~3ull, E)
+    }
   }
-  for (; tile < ntiles; tile += gridDim.x) {
-    unsigned long long *rp = rp0 + cur * (kFwRows + 2), *rpn = rp0 + (cur ^ 1) * (kFwRows + 2);
-    unsigned long long *mask_s = mask0 + cur * kFwRows, *maskn = mask0 + (cur ^ 1) * kFwRows;
-    const uint64_t rbase = a.r0 + tile * kFwRows;
-    const int nr = (int)((a.r1 - rbase) < (uint64_t)kFwRows ? (a.r1 - rbase) : (uint64_t)kFwRows);
+  __syncthreads();
+  for (uint64_t i = 0; i < nmine; ++i) {
+    const int slot = (int)(i % kFwSlots), slot1 = (int)((i + 1) % kFwSlots), slot3 = (int)((i + 3) % kFwSlots);
+    const unsigned long long *rp = rp0 + slot * (kFwRowSlots + 2);
+    const unsigned long long *mask_s = mask0 + slot * kFwRowSlots;
+    float *prod = prod0 + (i & 1) * kFwChunk;
+    const uint64_t tile = tile_of(i);
+    const int nr = tile_rows(tile);
     const unsigned long long B = rp[0], E = rp[nr];
-    const unsigned long long myb = trow < nr ? rp[trow] : E, mye = trow < nr ? rp[trow + 1] : E;
-    // row pointers and masks of the next tile, fetched before this tile's stream is waited for
-    const uint64_t next = tile + gridDim.x;
-    const bool has_next = next < ntiles;
-    const uint64_t rbase_n = a.r0 + next * kFwRows;
-    const int nrn = has_next ? (int)((a.r1 - rbase_n) < (uint64_t)kFwRows ? (a.r1 - rbase_n) : (uint64_t)kFwRows) : 0;
-    unsigned long long rp_next = 0, mk_next = 0;
-    if (has_next) {
-      if (tid <= nrn) rp_next = a.rowptr[rbase_n + tid];
-      if (dense && tid < nrn) mk_next = a.hmask[rbase_n + tid];
-    }
-    float rowsum = 0.0f;
-    unsigned long long cb = B & ~3ull;
-    FW_CONSUME(cb, B, E)
-    if (has_next) {
-      if (tid <= nrn) rpn[tid] = rp_next;
-      if (dense && tid < kFwRows) maskn[tid] = mk_next;
-    }
-    __syncthreads();  // products of the first chunk and the next tile's row pointers are in LDS
-    const bool multi = E > cb + kFwChunk;  // rows so long that the tile needs more passes
-    if (!multi && has_next) {
-      const unsigned long long Bn = rpn[0], En = rpn[nrn];
-      FW_ISSUE(Bn & ~3ull, En)
-    }
-    {
-      const unsigned long long s = myb > cb ? myb : cb;
-      const unsigned long long e = mye < cb + kFwChunk ? mye : cb + kFwChunk;
-      for (unsigned long long k = s + q; k < e; k += kFwLanesPerRow) rowsum += prod[k - cb];
-    }
-    if (multi) {
-      for (cb += kFwChunk; cb < E; cb += kFwChunk) {
+    const unsigned long long cb0 = B & ~3ull;
+    // tiles whose rows are so long that they do not fit one chunk take extra passes, each
+    // bracketed by two barriers that both roles execute
+    const bool has1 = i + 1 < nmine, has2 = i + 2 < nmine, has3 = i + 3 < nmine;
+    if (producer) {
+      // ---- producers --------------------------------------------------------------------------
+      uint32_t hi1 = 0;
+      // per-row results of the previous tile (the consumers left them in LDS: a store from a
+      // consumer wave would queue behind everything the producers have in the memory pipe)
+      if (i > 0) {
+        const uint64_t ptile = tile_of(i - 1);
+        if (ptid < tile_rows(ptile)) a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
+      }
+      // the streamed registers of the next tile are complete from here on (the compiler waits for
+      // them in front of this statement, not somewhere among the gathers below)
+#pragma unroll
+      for (int h = 0; h < H; ++h) asm volatile("" : "+v"(xc[h]), "+v"(xv[h])::"memory");
+      if (has2) {
+        const unsigned long long *rp2 = rp0 + (int)((i + 2) % kFwSlots) * (kFwRowSlots + 2);
+        const unsigned long long B2 = rp2[0], E2 = rp2[tile_rows(tile_of(i + 2))];
+        FW_ISSUE(yc, yv, B2 & ~3ull, E2)
+      }
+      // row data of the tile three ahead, parked in LDS after the wait below: producer threads
+      // 0..128 fetch row pointers and labels, the next 128 the masks
+      unsigned long long pf = 0;
+      float pf_lab = 0.0f;
+      int nr3 = 0;
+      if (has3) {
+        const uint64_t rb3 = a.r0 + tile_of(i + 3) * rpt;
+        nr3 = tile_rows(tile_of(i + 3));
+        if (ptid <= nr3) pf = a.rowptr[rb3 + ptid];
+        else if (dense && ptid > kFwRowSlots && ptid - (kFwRowSlots + 1) < nr3) pf = a.hmask[rb3 + ptid - (kFwRowSlots + 1)];
+        if (ptid < nr3) pf_lab = a.label[rb3 + ptid];
+      }
+      if (has1) {
+        const unsigned long long *rp1 = rp0 + slot1 * (kFwRowSlots + 2);
+        const unsigned long long B1 = rp1[0], E1 = rp1[tile_rows(tile_of(i + 1))];
+        FW_RANGE(B1, E1, lo1_, hi1_)
+        hi1 = hi1_;
+        FW_GATHER(lo1_, hi1_)
+      }
+      for (unsigned long long cb = cb0 + kFwChunk; cb < E; cb += kFwChunk) {
         __syncthreads();
-        FW_ISSUE(cb, E)
-        FW_CONSUME(cb, B, E)
         __syncthreads();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (has1) {
+        float *prodn = prod0 + ((i + 1) & 1) * kFwChunk;
+        FW_PRODUCTS(prodn, hi1)
+      }
+      if (has3) {
+        if (ptid <= nr3) rp0[slot3 * (kFwRowSlots + 2) + ptid] = pf;
+        else if (ptid > kFwRowSlots && ptid <= 2 * kFwRowSlots) mask0[slot3 * kFwRowSlots + ptid - (kFwRowSlots + 1)] = pf;
+        if (ptid < kFwRowSlots) lab0[slot3 * kFwRowSlots + ptid] = pf_lab;
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        xc[h] = yc[h];
+        xv[h] = yv[h];
+      }
+    } else {
+      // ---- consumers --------------------------------------------------------------------------
+      float rowsum = 0.0f;
+      {
+        // lane q of a row adds every second product of the row, four per trip; a read past the
+        // row's end stays inside LDS and is discarded
+        const unsigned long long myb = trow < nr ? rp[trow] : E, mye = trow < nr ? rp[trow + 1] : E;
+        const uint32_t s = (uint32_t)(myb - cb0);
+        const uint32_t e = (uint32_t)((mye < cb0 + kFwChunk ? mye : cb0 + kFwChunk) - cb0);
+        for (uint32_t k = s + q; k < e; k += 4 * kFwLanesPerRow) {
+          const float v0 = prod[k], v1 = prod[k + kFwLanesPerRow], v2 = prod[k + 2 * kFwLanesPerRow],
+                      v3 = prod[k + 3 * kFwLanesPerRow];
+          rowsum += v0;
+          rowsum += k + kFwLanesPerRow < e ? v1 : 0.0f;
+          rowsum += k + 2 * kFwLanesPerRow < e ? v2 : 0.0f;
+          rowsum += k + 3 * kFwLanesPerRow < e ? v3 : 0.0f;
+        }
+      }
+      for (unsigned long long cb = cb0 + kFwChunk; cb < E; cb += kFwChunk) {
+        // the rest of an oversized tile goes through the same half of the product buffer, chunk
+        // by chunk, with plain loads
+        __syncthreads();
+        const unsigned long long ce = E < cb + kFwChunk ? E : cb + kFwChunk;
+        for (unsigned long long k = cb + tid; k < ce; k += kFwConsumers) {
+          const uint32_t c = a.col[k];
+          const float v = hasval ? a.val[k] : 1.0f;
+          prod[k - cb] = (c < nhot ? hot[c] : wsum[c]) * v;
+        }
+        __syncthreads();
+        const unsigned long long myb = trow < nr ? rp[trow] : E, mye = trow < nr ? rp[trow + 1] : E;
         const unsigned long long s = myb > cb ? myb : cb;
-        const unsigned long long e = mye < cb + kFwChunk ? mye : cb + kFwChunk;
+        const unsigned long long e = mye < ce ? mye : ce;
         for (unsigned long long k = s + q; k < e; k += kFwLanesPerRow) rowsum += prod[k - cb];
       }
-      if (has_next) {
-        const unsigned long long Bn = rpn[0], En = rpn[nrn];
-        FW_ISSUE(Bn & ~3ull, En)
-      }
-    }
-    if (dense && trow < nr) {
-      const unsigned long long m = mask_s[trow];
-      rowsum += tab[(2 * q) * 256 + (int)((m >> (16 * q)) & 255)] +
-                tab[(2 * q + 1) * 256 + (int)((m >> (16 * q + 8)) & 255)];
-    }
+      if (dense && trow < nr) {
+        const unsigned long long m = mask_s[trow];
+        constexpr int kBytesPerLane = 8 / kFwLanesPerRow;
 #pragma unroll
-    for (int off = 1; off < kFwLanesPerRow; off <<= 1) rowsum += __shfl_xor(rowsum, off, 64);
-    if (q == 0 && trow < nr) {
-      const uint64_t myrow = rbase + trow;
-      const float m = rowsum;
-      const float lab = a.label[myrow];
-      if (MODE == FWD_EVAL) {
-        // src/metrics.cc:104-105: double predict, -log p / -log(1-p)
-        const double pd = 1.0f / (1 + exp(-(double)clamp35(m)));
-        a.out[myrow] = (float)pd;
-        acc0 += lab > 0 ? -log(pd) : -log(1 - pd);
-      } else if (MODE == FWD_LBFGS) {
-        const float t = lab > 0 ? 1.0f : 0.0f;
-        const float loss = log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f));
-        const float res = 1.0f / (1.0f + expf(-m)) - t;
-        a.out[myrow] = res;
-        if (dense) rfx_s[trow] = (unsigned long long)(long long)(res * a.scale);
-        acc0 += (double)loss;
-        acc1 += (double)res;
-      } else {
-        // src/ftrl.cc:72,76-78
-        const float p = (float)(1.0 / (1 + exp(-(double)clamp35(m))));
-        const int y = lab > 0 ? 1 : 0;
-        const float g = p - y;
-        a.out[myrow] = g;
-        if (dense) {
-          rfx_s[trow] = (unsigned long long)(long long)(g * a.scale);
-          rfx2_s[trow] = (unsigned long long)(long long)(g * g * a.scale);
+        for (int b8 = 0; b8 < kBytesPerLane; ++b8) {
+          const int g = q * kBytesPerLane + b8;
+          rowsum += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
         }
-        acc0 += (double)g;
-        acc1 += (double)(g * g);
+      }
+#pragma unroll
+      for (int off = 1; off < kFwLanesPerRow; off <<= 1) rowsum += __shfl_xor(rowsum, off, 64);
+      // Epilogue on the first lane of each row; everything a consumer wave needs afterwards (its
+      // 32 rows' residuals and masks) stays inside the wave, so the consumers need no barrier
+      // of their own.
+      unsigned long long my_r = 0, my_r2 = 0;
+      const unsigned long long my_m = (dense && trow < nr) ? mask_s[trow] : 0ull;
+      if (q == 0 && trow < nr) {
+        const float m = rowsum;
+        const float lab = lab0[slot * kFwRowSlots + trow];
+        if (MODE == FWD_EVAL) {
+          // src/metrics.cc:104-105: double predict, -log p / -log(1-p)
+          const double pd = 1.0f / (1 + exp(-(double)clamp35(m)));
+          out_s[trow] = (float)pd;
+          acc0 += lab > 0 ? -log(pd) : -log(1 - pd);
+        } else if (MODE == FWD_LBFGS) {
+          const float t = lab > 0 ? 1.0f : 0.0f;
+          const float loss = log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f));
+          const float res = 1.0f / (1.0f + expf(-m)) - t;
+          out_s[trow] = res;
+          my_r = (unsigned long long)(long long)(res * a.scale);
+          acc0 += (double)loss;
+          acc1 += (double)res;
+        } else {
+          // src/ftrl.cc:72,76-78
+          const float p = (float)(1.0 / (1 + exp(-(double)clamp35(m))));
+          const int y = lab > 0 ? 1 : 0;
+          const float g = p - y;
+          out_s[trow] = g;
+          my_r = (unsigned long long)(long long)(g * a.scale);
+          my_r2 = (unsigned long long)(long long)(g * g * a.scale);
+          acc0 += (double)g;
+          acc1 += (double)(g * g);
+        }
+      }
+      if (colsums) {
+        // X^T r restricted to the mask columns: row r of this wave lives in lane r * lanes-per-row;
+        // lane k adds the rows whose mask has bit k
+        constexpr int kRowsPerWave = 64 / kFwLanesPerRow;
+        const int r0w = wave * kRowsPerWave;
+        const int nrw = nr - r0w < kRowsPerWave ? nr - r0w : kRowsPerWave;
+        for (int r = 0; r < nrw; ++r) {
+          const unsigned long long m = __shfl(my_m, r * kFwLanesPerRow, 64);
+          const unsigned long long rv = __shfl(my_r, r * kFwLanesPerRow, 64);
+          const bool on = (m >> lane) & 1ull;
+          h1 += on ? rv : 0ull;
+          if (MODE == FWD_FTRL) {
+            const unsigned long long rv2 = __shfl(my_r2, r * kFwLanesPerRow, 64);
+            h2 += on ? rv2 : 0ull;
+            hseen |= m;
+          }
+        }
       }
     }
-    __syncthreads();  // the residuals of the tile are in LDS; prod may be overwritten
-    if (dense && MODE != FWD_EVAL) {
-      // X^T r restricted to the mask columns: every wave takes 16 rows of the tile, lane k adds
-      // the rows whose mask has bit k
-      constexpr int kRowsPerWave = kFwRows / (kFwThreads / 64);
-#pragma unroll 4
-      for (int i = 0; i < kRowsPerWave; ++i) {
-        const int rr = wave * kRowsPerWave + i;
-        const unsigned long long m = rr < nr ? mask_s[rr] : 0ull;
-        const bool on = (m >> lane) & 1ull;
-        h1 += on ? rfx_s[rr] : 0ull;
-        if (MODE == FWD_FTRL) h2 += on ? rfx2_s[rr] : 0ull;
-        hseen |= m;
-      }
-      __syncthreads();  // masks / residuals are rewritten during the next tile
-    }
-    cur ^= 1;
+    __syncthreads();
+  }
+  if (producer && nmine > 0) {
+    const uint64_t ptile = tile_of(nmine - 1);
+    if (ptid < tile_rows(ptile)) a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
   }
 #undef FW_ISSUE
-#undef FW_CONSUME
-  if (dense && MODE != FWD_EVAL) {
+#undef FW_GATHER
+#undef FW_PRODUCTS
+#undef FW_RANGE
+  if (colsums) {
     // combine the waves' column sums and add them to the global accumulators
     for (int pass = 0; pass < (MODE == FWD_FTRL ? 2 : 1); ++pass) {
       __syncthreads();
@@ -266,7 +416,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       __syncthreads();
       if (tid < 64) {
         unsigned long long t = 0;
-        for (int i = 0; i < kFwThreads / 64; ++i) t += hsum[i][tid];
+        for (int w8 = 0; w8 < kFwThreads / 64; ++w8) t += hsum[w8][tid];
         if (t) atomicAdd((pass == 0 ? a.g1 : a.g2) + a.perm[tid], t);
       }
     }
@@ -276,7 +426,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       __syncthreads();
       if (tid < 64) {
         unsigned long long seen = 0;
-        for (int i = 0; i < kFwThreads / 64; ++i) seen |= hsum[i][0];
+        for (int w8 = 0; w8 < kFwThreads / 64; ++w8) seen |= hsum[w8][0];
         if ((seen >> tid) & 1ull) {
           const uint32_t o = a.perm[tid];
           atomicOr(&a.gmask[o >> 5], 1u << (o & 31));
@@ -293,7 +443,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   __syncthreads();
   if (tid == 0) {
     double t = 0;
-    for (int i = 0; i < kFwThreads / 64; ++i) t += shred[i];
+    for (int w8 = 0; w8 < kFwThreads / 64; ++w8) t += shred[w8];
     a.partials[0 * kMaxPartialBlocks + blockIdx.x] = t;
   }
   __syncthreads();
@@ -301,7 +451,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   __syncthreads();
   if (tid == 0) {
     double t = 0;
-    for (int i = 0; i < kFwThreads / 64; ++i) t += shred[i];
+    for (int w8 = 0; w8 < kFwThreads / 64; ++w8) t += shred[w8];
     a.partials[1 * kMaxPartialBlocks + blockIdx.x] = t;
   }
 }
@@ -359,6 +509,7 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.partials = ctx->d_partials;
   a.mode = (int)mode;
   a.nhot = (uint32_t)std::min<uint64_t>(kFwHot, csr->dim);
+  a.dim = (uint32_t)csr->dim;
   static bool raised = false;
   if (!raised) {
     for (const void *fn : {reinterpret_cast<const void *>(&k_forward<FWD_EVAL>),
@@ -367,7 +518,14 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
       ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds));
     raised = true;
   }
-  const uint64_t ntiles = (r1 - r0 + kFwRows - 1) / kFwRows;
+  // rows per tile: as many as normally fit one chunk of stored entries, with some headroom
+  {
+    const uint64_t entries = csr->hot_dense ? csr->cnnz : csr->nnz;
+    const double avg = csr->nrows ? (double)entries / (double)csr->nrows : 1.0;
+    const double fit = 0.82 * kFwChunk / std::max(avg, 1.0);
+    a.rows_per_tile = (uint32_t)std::min<double>(kFwRowSlots, std::max(8.0, std::floor(fit / 8.0) * 8.0));
+  }
+  const uint64_t ntiles = (r1 - r0 + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = grid_for(ntiles * kFwThreads, kFwThreads, ctx->cu_count);
   *nblocks_out = grid;
   KernelTimer t(ctx, mode == FWD_EVAL ? ADMM_K_FORWARD_EVAL : ADMM_K_FORWARD);
