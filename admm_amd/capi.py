@@ -35,7 +35,8 @@ class AdmmError(RuntimeError):
 class SynthSpec(C.Structure):
     _fields_ = [("nrows", C.c_uint64), ("dim", C.c_uint64), ("seed", C.c_uint64),
                 ("model_seed", C.c_uint64), ("row_offset", C.c_uint64), ("mean_nnz", C.c_float), ("zipf_s", C.c_float),
-                ("len_dist", C.c_int), ("tail_sigma", C.c_float), ("max_len", C.c_uint32)]
+                ("len_dist", C.c_int), ("tail_sigma", C.c_float), ("max_len", C.c_uint32),
+                ("explicit_values", C.c_int)]
 
 
 class LbfgsParams(C.Structure):
@@ -209,11 +210,12 @@ class Context:
         return SampleSet(self, h)
 
     def csr_synth(self, nrows, dim, mean_nnz, seed=20251111, row_offset=0, zipf_s=1.1,
-                  len_dist=0, tail_sigma=1.0, max_len=None, model_seed=7):
+                  len_dist=0, tail_sigma=1.0, max_len=None, model_seed=7, explicit_values=False):
         if max_len is None:
             max_len = int(min(1024, max(8, 4 * mean_nnz)))
         spec = SynthSpec(int(nrows), int(dim), int(seed), int(model_seed), int(row_offset), float(mean_nnz),
-                         float(zipf_s), int(len_dist), float(tail_sigma), int(max_len))
+                         float(zipf_s), int(len_dist), float(tail_sigma), int(max_len),
+                         1 if explicit_values else 0)
         h = C.c_void_p()
         _check(self.L.admm_csr_synth(self.h, C.byref(spec), C.byref(h)))
         return SampleSet(self, h)

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
       const uint32_t before = outn + __popcll(m & ((1ull << lane) - 1ull));
       if (WRITE && keep) {
         a.col[ob + 1 + before] = id + 1u;
-        a.val[ob + 1 + before] = 1.0f;
+        if (a.val) a.val[ob + 1 + before] = 1.0f;
         margin += wstar_of(a.s.model_seed, id);
       }
       __syncthreads();
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
       for (int off = 32; off > 0; off >>= 1) margin += __shfl_down(margin, off, 64);
       if (lane == 0) {
         a.col[ob] = 0u;
-        a.val[ob] = 1.0f;
+        if (a.val) a.val[ob] = 1.0f;
         const float p = 1.0f / (1.0f + expf(-(margin - 0.5f)));
         a.label[r] = u01(mix64(hrow ^ 0x1234567ull)) < p ? 1.0f : 0.0f;
       }
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ ro
       if (FILL && cold) {
         const uint64_t pos = out + __popc(gm & ((1u << sub) - 1u));
         ccol[pos] = c;
-        cval[pos] = v;
+        if (cval) cval[pos] = v;
       }
       out += __popc(gm);
       ncold += __popc(gm);
@@ -450,7 +450,16 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
   c->has_bias = add_bias != 0;
   c->has_dup_cols = dup;
   c->nnz = add_bias ? nnz + nrows : nnz;
-  const bool keep_val = val != nullptr || add_bias;  // the bias entry carries an explicit 1
+  // a set whose stored values are all 1 (binary features, the common case for this model) is kept
+  // as a pattern matrix: no value array, the kernels read an implicit 1
+  bool unit = true;
+  if (val)
+    for (uint64_t k = 0; k < nnz; ++k)
+      if (val[k] != 1.0f) {
+        unit = false;
+        break;
+      }
+  const bool keep_val = !unit;
   int rc = ADMM_OK;
   auto fail = [&](int code) {
     free_csr(c);
@@ -472,7 +481,7 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
   if (!add_bias) {
     UP_CHECK(hipMemcpyAsync(c->d_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
     if (nnz) UP_CHECK(hipMemcpyAsync(c->d_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
-    if (val && nnz) UP_CHECK(hipMemcpyAsync(c->d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    if (keep_val && nnz) UP_CHECK(hipMemcpyAsync(c->d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
     UP_CHECK(hipStreamSynchronize(ctx->stream));
   } else {
     uint64_t *t_rowptr = nullptr;
@@ -480,10 +489,10 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
     float *t_val = nullptr;
     UP_CHECK(hipMalloc(&t_rowptr, sizeof(uint64_t) * (nrows + 1)));
     UP_CHECK(hipMalloc(&t_col, sizeof(uint32_t) * std::max<uint64_t>(nnz, 1)));
-    if (val) UP_CHECK(hipMalloc(&t_val, sizeof(float) * std::max<uint64_t>(nnz, 1)));
+    if (keep_val) UP_CHECK(hipMalloc(&t_val, sizeof(float) * std::max<uint64_t>(nnz, 1)));
     UP_CHECK(hipMemcpyAsync(t_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
     if (nnz) UP_CHECK(hipMemcpyAsync(t_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
-    if (val && nnz) UP_CHECK(hipMemcpyAsync(t_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    if (keep_val && nnz) UP_CHECK(hipMemcpyAsync(t_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
     if (nrows) {
       const int grid = grid_for(nrows * 16, 256, ctx->cu_count * 8);
       hipLaunchKernelGGL(k_translate, dim3(grid), dim3(256), 0, ctx->stream, t_rowptr, t_col, t_val,
@@ -626,7 +635,7 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
     RL_CHECK(se);
     csr->cnnz = total;
     RL_CHECK(hipMalloc(&csr->d_ccol, sizeof(uint32_t) * (total + 8)));
-    RL_CHECK(hipMalloc(&csr->d_cval, sizeof(float) * (total + 8)));
+    if (csr->d_val) RL_CHECK(hipMalloc(&csr->d_cval, sizeof(float) * (total + 8)));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact<true>), dim3(cgrid), dim3(256), 0, ctx->stream, csr->d_rowptr,
                        csr->d_col, csr->d_val, n, nullptr, csr->d_crowptr, csr->d_ccol, csr->d_cval, nullptr);
     RL_CHECK(hipGetLastError());
@@ -813,7 +822,8 @@ extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_c
   if (e != hipSuccess) return fail("length pass", e);
   c->nnz = total;
   if ((e = hipMalloc(&c->d_col, sizeof(uint32_t) * (total + 8))) != hipSuccess) return fail("col", e);
-  if ((e = hipMalloc(&c->d_val, sizeof(float) * (total + 8))) != hipSuccess) return fail("val", e);
+  // the generated values are all 1: stored only on request
+  if (spec->explicit_values && (e = hipMalloc(&c->d_val, sizeof(float) * (total + 8))) != hipSuccess) return fail("val", e);
   a.rowptr = c->d_rowptr;
   a.col = c->d_col;
   a.val = c->d_val;

@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20251111)
+    ap.add_argument("--explicit-values", action="store_true",
+                    help="store the generated values (all 1.0) as an f32 array instead of keeping the set as "
+                         "a pattern matrix, which is how the library keeps any all-ones sample set")
     return ap.parse_args()
 
 
@@ -54,7 +57,8 @@ def cpu_baseline(ctx, args, rho):
     from oracle import oracle as orc
     orc.build()
     n = args.cpu_sample_rows
-    dev = ctx.csr_synth(n, args.dim, args.mean_nnz, seed=args.seed, row_offset=0)
+    dev = ctx.csr_synth(n, args.dim, args.mean_nnz, seed=args.seed, row_offset=0,
+                        explicit_values=args.explicit_values)
     csr = orc.Csr(*dev.download(), args.dim)
     dev.destroy()
     x = np.zeros(args.dim, np.float32)
@@ -104,11 +108,13 @@ def main():
     rows_total = args.rows
     r0, r1 = adist.shard_range(rows_total, rank, world)
     t_gen = time.perf_counter()
-    train = ctx.csr_synth(r1 - r0, args.dim, args.mean_nnz, seed=args.seed, row_offset=r0)
+    train = ctx.csr_synth(r1 - r0, args.dim, args.mean_nnz, seed=args.seed, row_offset=r0,
+                          explicit_values=args.explicit_values)
     train.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
     train.relabel_by_frequency()
     n_test = max(1, int((r1 - r0) * args.test_frac))
-    test = ctx.csr_synth(n_test, args.dim, args.mean_nnz, seed=args.seed + 1, row_offset=r0)
+    test = ctx.csr_synth(n_test, args.dim, args.mean_nnz, seed=args.seed + 1, row_offset=r0,
+                         explicit_values=args.explicit_values)
     test.relabel_by_frequency()
     ctx.sync()
     t_gen = time.perf_counter() - t_gen
@@ -162,7 +168,8 @@ def main():
         rows = r1 - r0
         # algorithmic HBM bytes of one launch over this rank's shard (idx u32 + val f32 per stored
         # entry; rowptr 8 + label 4 + residual 4 per row forward, residual 4 per row transposed;
-        # one dim-sized vector each)
+        # one dim-sized vector each).  The figure is a property of the problem, not of the storage:
+        # a pattern-matrix set moves fewer bytes than this, as do the entries held in row masks.
         tnnz = train.nnz - rows                       # the bias column is reduced by the forward sweep
         fwd_bytes = 8.0 * train.nnz + 16.0 * rows + 4.0 * args.dim
         tr_bytes = 8.0 * tnnz + 4.0 * rows + 4.0 * args.dim
@@ -183,7 +190,8 @@ def main():
         if os.path.exists(tfile):
             pmc = json.load(open(tfile))
             wl = pmc.get("workload", {})
-            if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus")) == (rows_total, args.dim, world):
+            if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus"), bool(wl.get("explicit_values"))) == \
+                    (rows_total, args.dim, world, args.explicit_values):
                 sym = "k_transposed<false" if dom == "transposed_block_sweep" else "k_forward<1>"
                 for name, rec in pmc["kernels"].items():
                     if sym in name:
@@ -205,6 +213,8 @@ def main():
                 "workload": "ADMM-LR L1+L2, synthetic %d rows x %d features, ~%d nnz/row, row-sharded over %d GPU(s)"
                             % (rows_total, args.dim, round(nnz_total / rows_total), world),
                 "local_solver": "lbfgs (max_iter %d)" % args.lbfgs_iters,
+                "values": "all 1.0, stored as f32" if args.explicit_values else
+                          "all 1.0, implicit (pattern matrix: no value arrays in HBM)",
                 "rows_total": rows_total, "dim": args.dim, "nnz_total": nnz_total,
                 "objective_gradient_evals_total": evals_total,
                 "admm_iterations_per_s": args.steps / dt,

@@ -96,6 +96,8 @@ typedef struct admm_synth_spec {
   int len_dist;        /* 0: ~Poisson(mean_nnz); 1: log-normal heavy tail with the same mean */
   float tail_sigma;    /* log-normal sigma for len_dist 1 */
   uint32_t max_len;    /* raw row length cap, <= 1024 */
+  int explicit_values; /* the generated values are all 1.0: 0 keeps the set as a pattern matrix
+                          (no value array, as an uploaded all-ones set is kept), 1 stores them */
 } admm_synth_spec;
 int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_csr **out);
 

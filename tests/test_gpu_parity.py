@@ -290,8 +290,25 @@ def test_synth_generator_properties(ctx):
     rp2, col2, _, lab2 = b.download()
     np.testing.assert_array_equal(col2, col[rowptr[2000]:rowptr[3000]])
     np.testing.assert_array_equal(lab2, label[2000:3000])
+    # the values (all 1) are stored only on request; both forms are the same sample set and give
+    # the same objective and gradient
+    c = ctx.csr_synth(5000, dim, 40, seed=7, explicit_values=True)
+    rp3, col3, val3, lab3 = c.download()
+    np.testing.assert_array_equal(col3, col)
+    np.testing.assert_array_equal(lab3, label)
+    assert (val3 == 1.0).all()
+    assert c.bytes()[0] == a.bytes()[0] + 4 * a.nnz
+    x = ctx.vec(dim, np.random.default_rng(1).normal(0, 0.1, dim).astype(np.float32))
+    ga, gc = ctx.vec(dim), ctx.vec(dim)
+    a.build_transposed().relabel_by_frequency()
+    c.build_transposed().relabel_by_frequency()
+    fa = a.logistic_fg(x, ga, rho=0.0)
+    fc = c.logistic_fg(x, gc, rho=0.0)
+    assert fa == fc
+    np.testing.assert_array_equal(ga.download(), gc.download())
     a.destroy()
     b.destroy()
+    c.destroy()
 
 
 def test_sweeps_on_generated_set(ctx, oracle):

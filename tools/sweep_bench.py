@@ -27,6 +27,7 @@ x, g = ctx.vec(args.dim), ctx.vec(args.dim)
 import numpy as np
 x.upload(np.random.default_rng(0).normal(0, 0.05, args.dim).astype(np.float32))
 rows, nnz = s.nrows, s.nnz
+print("hbm bytes: row-major %d, column-block copy %d" % s.bytes(), flush=True)
 fb = 8.0 * nnz + 16.0 * rows + 4.0 * args.dim
 tb = 8.0 * (nnz - rows) + 4.0 * rows + 4.0 * args.dim
 for ab in args.ablate.split(","):
