@@ -44,12 +44,21 @@ class Runtime {
   int GetWorldSize() const { return world_; }
   admm_ctx *ctx() const { return ctx_; }
   void TrackerPrintf(const char *fmt, ...) const;
-  // in-place float sum over ranks of a device buffer
+  // in-place float sum over ranks of a device buffer: RCCL, or -- when several ranks share one GPU
+  // (ADMM_ALLREDUCE=shm, set by the local launcher) -- a host shared-memory segment in which every
+  // rank adds the ranks' buffers in rank order
   void AllreduceSum(float *device_buf, size_t n);
 
  private:
+  void ShmAllreduce(float *device_buf, size_t n);
+  void ShmBarrier();
   int rank_ = 0, world_ = 1;
   admm_ctx *ctx_ = nullptr;
+  bool use_shm_ = false;
+  std::string shm_path_;
+  void *shm_ = nullptr;
+  size_t shm_bytes_ = 0, shm_n_ = 0;
+  uint32_t shm_sense_ = 0;
 };
 
 // dim floats in HBM with value semantics close enough to std::vector<float> for the mains

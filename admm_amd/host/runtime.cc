@@ -1,4 +1,10 @@
 // Process set-up, device vectors and the all-reduce for the host programs.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstring>
@@ -31,11 +37,16 @@ void Runtime::Init(int, char *[]) {
   ADMM_CALL(admm_device_count(&ndev));
   const int dev = env_int("LOCAL_RANK", nullptr, rank_) % (ndev > 0 ? ndev : 1);
   ADMM_CALL(admm_ctx_create(dev, nullptr, &ctx_));
-  if (world_ > 1) {
+  const char *dir = std::getenv("ADMM_RENDEZVOUS_DIR");
+  const char *job = std::getenv("DMLC_TRACKER_PORT");
+  const std::string base = std::string(dir && *dir ? dir : "/tmp") + "/admm_";
+  const std::string jobid = job && *job ? job : "local";
+  const char *mode = std::getenv("ADMM_ALLREDUCE");
+  use_shm_ = world_ > 1 && mode && std::strcmp(mode, "shm") == 0;
+  shm_path_ = base + "shm_" + jobid;
+  if (world_ > 1 && !use_shm_) {
     // rank 0 publishes the communicator id in a file every rank can read
-    const char *dir = std::getenv("ADMM_RENDEZVOUS_DIR");
-    const char *job = std::getenv("DMLC_TRACKER_PORT");
-    std::string path = std::string(dir && *dir ? dir : "/tmp") + "/admm_uid_" + (job && *job ? job : "local");
+    std::string path = base + "uid_" + jobid;
     char id[128];
     if (rank_ == 0) {
       ADMM_CALL(admm_comm_unique_id(id));
@@ -57,6 +68,12 @@ void Runtime::Init(int, char *[]) {
 }
 
 void Runtime::Finalize() {
+  if (shm_) {
+    ShmBarrier();
+    munmap(shm_, shm_bytes_);
+    shm_ = nullptr;
+    if (rank_ == 0) unlink(shm_path_.c_str());
+  }
   if (ctx_) admm_ctx_destroy(ctx_);
   ctx_ = nullptr;
 }
@@ -69,7 +86,78 @@ void Runtime::TrackerPrintf(const char *fmt, ...) const {
   std::fflush(stdout);
 }
 
-void Runtime::AllreduceSum(float *device_buf, size_t n) { ADMM_CALL(admm_allreduce_sum_f32(ctx_, device_buf, n)); }
+void Runtime::AllreduceSum(float *device_buf, size_t n) {
+  if (world_ == 1) return;
+  if (use_shm_) ShmAllreduce(device_buf, n);
+  else ADMM_CALL(admm_allreduce_sum_f32(ctx_, device_buf, n));
+}
+
+// ---- all-reduce through host shared memory ------------------------------------------------------
+//
+// Segment layout: a header of two counters (arrivals, generation), then one slot of n floats per
+// rank.  Rank 0 creates the file at the first call (the length n is known then); the others wait
+// for it to reach its full size.
+
+namespace {
+struct ShmHeader {
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> generation;
+  char pad[56];
+};
+static_assert(sizeof(ShmHeader) == 64, "header is one cache line");
+}  // namespace
+
+void Runtime::ShmBarrier() {
+  ShmHeader *h = static_cast<ShmHeader *>(shm_);
+  const uint32_t gen = h->generation.load(std::memory_order_acquire);
+  if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world_) {
+    h->arrived.store(0, std::memory_order_relaxed);
+    h->generation.store(gen + 1, std::memory_order_release);
+  } else {
+    for (uint64_t spins = 0; h->generation.load(std::memory_order_acquire) == gen; ++spins) {
+      if (spins > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      ADMM_CHECK(spins < 20000000ull);  // a rank died: give up after about a quarter of an hour
+    }
+  }
+}
+
+void Runtime::ShmAllreduce(float *device_buf, size_t n) {
+  if (!shm_) {
+    shm_n_ = n;
+    shm_bytes_ = sizeof(ShmHeader) + sizeof(float) * n * (size_t)world_;
+    int fd = -1;
+    if (rank_ == 0) {
+      const std::string tmp = shm_path_ + ".tmp";
+      fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600);
+      ADMM_CHECK(fd >= 0);
+      ADMM_CHECK(ftruncate(fd, (off_t)shm_bytes_) == 0);  // zero-filled: counters start at 0
+      ADMM_CHECK(std::rename(tmp.c_str(), shm_path_.c_str()) == 0);
+    } else {
+      for (int tries = 0;; ++tries) {
+        struct stat st;
+        fd = open(shm_path_.c_str(), O_RDWR);
+        if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size == shm_bytes_) break;
+        if (fd >= 0) close(fd);
+        ADMM_CHECK(tries < 6000);  // ten minutes
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      }
+    }
+    shm_ = mmap(nullptr, shm_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    ADMM_CHECK(shm_ != MAP_FAILED);
+  }
+  ADMM_CHECK(n == shm_n_);  // the reference reduces one length only (dim)
+  float *slots = reinterpret_cast<float *>(static_cast<char *>(shm_) + sizeof(ShmHeader));
+  ADMM_CALL(admm_vec_download(ctx_, slots + (size_t)rank_ * n, device_buf, n));
+  ShmBarrier();
+  std::vector<float> sum(slots, slots + n);  // rank 0's slot, then the others in rank order
+  for (int r = 1; r < world_; ++r) {
+    const float *s = slots + (size_t)r * n;
+    for (size_t i = 0; i < n; ++i) sum[i] += s[i];
+  }
+  ShmBarrier();  // nobody refills its slot before every rank has read all of them
+  ADMM_CALL(admm_vec_upload(ctx_, device_buf, sum.data(), n));
+}
 
 DeviceVector &DeviceVector::operator=(const DeviceVector &o) {
   if (this == &o) return *this;

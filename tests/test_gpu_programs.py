@@ -152,3 +152,61 @@ def test_ftrl_and_evan_programs(tmp_path, oracle):
     m = re.search(r"^test \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out, flags=re.M)
     assert m and float(m.group(1)) == pytest.approx(expect[-1][0], rel=2e-5)
     assert float(m.group(2)) == pytest.approx(expect[-1][1], rel=5e-5)
+
+
+def test_three_workers_under_the_local_launcher(tmp_path, oracle):
+    """`dmlc_local.py -n 3 ./admm admm.conf ...`: three ranks (sharing the one GPU of the test box, so
+    the all-reduce goes through host shared memory), one psid each, against the reference loop"""
+    dim = 200
+    names = ["A", "B", "C"]
+    for k, name in enumerate(names):
+        write_libsvm(str(tmp_path / "train" / (name + "_aggregated") / "part-00000"),
+                     make_synth_csr(700 + 50 * k, dim, 10, seed=201 + k, binary=(k != 1)))
+        write_libsvm(str(tmp_path / "test" / (name + "_aggregated") / "part-00000"),
+                     make_synth_csr(200, dim, 10, seed=211 + k))
+    os.makedirs(tmp_path / "out")
+    conf = tmp_path / "admm.conf"
+    conf.write_text("step_size = 0.01\nbias_var = 0.01\nglobal_var = 4\nftrl_alpha = 0.1\npasses = 3\n"
+                    "dim = %d\nA : 1\nB : 1\nC : 1\n" % dim)
+    out = _run([os.path.join(ROOT, "tools", "dmlc_local.py"), "-n", "3", "--allreduce", "shm",
+                os.path.join(BIN, "admm"), str(conf), str(tmp_path / "train"), str(tmp_path / "test"),
+                str(tmp_path / "out")])
+    parts = [[oracle.translate(oracle.parse_libsvm(str(tmp_path / "train" / (n + "_aggregated") / "part-00000")))]
+             for n in names]
+    tests = [oracle.translate(oracle.parse_libsvm(str(tmp_path / "test" / (n + "_aggregated") / "part-00000")))
+             for n in names]
+    for p in parts:
+        p[0].dim = dim
+    cfg = oracle.AdmmConf(step_size=0.01, global_var=4, ftrl_alpha=0.1, passes=3, dim=dim, bias_var=0.01)
+    workers, zg, rec = oracle.admm_run(parts, tests, cfg)
+    for k, name in enumerate(names):
+        lines = re.findall(r"^%s \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$" % name, out, flags=re.M)
+        assert len(lines) == 3
+        for (l, a, n), r in zip(lines, rec):
+            assert int(n) == 200
+            assert float(l) == pytest.approx(r["lines"][k][0], rel=2e-5)
+            assert float(a) == pytest.approx(r["lines"][k][1], rel=5e-5)
+        x = _read_sparse_sections(tmp_path / "out" / ("admm_weight_" + name))[0]
+        np.testing.assert_allclose(x, workers[k].x, rtol=2e-5, atol=1e-6 * max(1.0, np.abs(workers[k].x).max()))
+    assert [int(x) for x in re.findall(r"^Finish (\d+)-th iteration$", out, flags=re.M)] == [0, 1, 2]
+
+
+def test_launcher_restarts_on_254_and_reports_failures(tmp_path):
+    """the keep-alive contract of the reference's launcher: exit code 254 means "start me again"; this
+    part needs no GPU work, the workers are shell one-liners"""
+    marker = tmp_path / "seen"
+    script = tmp_path / "w.sh"
+    script.write_text("#!/bin/bash\n"
+                      "echo \"$DMLC_TASK_ID/$DMLC_NUM_WORKER/$DMLC_ROLE/$DMLC_NUM_ATTEMPT\" >> %s\n"
+                      "if [ \"$DMLC_TASK_ID\" = 1 ] && [ \"$DMLC_NUM_ATTEMPT\" = 0 ]; then exit 254; fi\n"
+                      "exit 0\n" % marker)
+    os.chmod(script, 0o755)
+    _run([os.path.join(ROOT, "tools", "dmlc_local.py"), "-n", "2", str(script)])
+    seen = sorted(open(marker).read().split())
+    assert seen == ["0/2/worker/0", "1/2/worker/0", "1/2/worker/1"]
+    bad = tmp_path / "bad.sh"
+    bad.write_text("#!/bin/bash\nif [ \"$DMLC_TASK_ID\" = 0 ]; then exit 3; fi\nsleep 30\n")
+    os.chmod(bad, 0o755)
+    r = subprocess.run([os.path.join(ROOT, "tools", "dmlc_local.py"), "-n", "2", str(bad)],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3
