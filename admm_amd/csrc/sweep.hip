@@ -522,7 +522,7 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   {
     const uint64_t entries = csr->hot_dense ? csr->cnnz : csr->nnz;
     const double avg = csr->nrows ? (double)entries / (double)csr->nrows : 1.0;
-    const double fit = 0.82 * kFwChunk / std::max(avg, 1.0);
+    const double fit = 0.94 * kFwChunk / std::max(avg, 1.0);
     a.rows_per_tile = (uint32_t)std::min<double>(kFwRowSlots, std::max(8.0, std::floor(fit / 8.0) * 8.0));
   }
   const uint64_t ntiles = (r1 - r0 + a.rows_per_tile - 1) / a.rows_per_tile;
