@@ -187,7 +187,6 @@ struct SynthArgs {
   int kbits;
   float zipf_a, zipf_top;  // a = 1 - s ; top = (nfeat+1)^a - 1
   float ln_mu;
-  int noscatter;  // development switch: keep ids equal to their frequency rank
   uint64_t *rowlen;        // pass 1 output (entries per row incl. bias)
   const uint64_t *rowptr;  // pass 2 input
   uint32_t *col;
@@ -224,7 +223,7 @@ __global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
         uint32_t rank = (uint32_t)x;
         rank = rank < 1 ? 0 : rank - 1;
         if (rank >= a.nfeat) rank = a.nfeat - 1;
-        id = a.noscatter ? rank : scatter_id(rank, a.nfeat, a.kbits);
+        id = scatter_id(rank, a.nfeat, a.kbits);
       }
       ids[k] = id;
     }
@@ -786,7 +785,6 @@ extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_c
   a.zipf_a = 1.0f - spec->zipf_s;
   a.zipf_top = powf((float)a.nfeat + 1.0f, a.zipf_a) - 1.0f;
   a.ln_mu = logf(spec->mean_nnz) - 0.5f * spec->tail_sigma * spec->tail_sigma;
-  a.noscatter = getenv("ADMM_SYNTH_NOSCATTER") != nullptr;
   auto fail = [&](const char *what, hipError_t e) {
     set_error("admm_csr_synth: %s: %s", what, hipGetErrorString(e));
     free_csr(c);

@@ -412,7 +412,7 @@ int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const floa
   a.beta = beta;
   a.l1 = l1;
   a.l2 = l2;
-  if (!csr->has_dup_cols && !getenv("ADMM_FTRL_FENCED")) ADMM_TRY(ensure_dep(csr));
+  if (!csr->has_dup_cols) ADMM_TRY(ensure_dep(csr));
   KernelTimer t(ctx, ADMM_K_FTRL_SEQ);
   if (csr->has_dup_cols)
     hipLaunchKernelGGL(k_ftrl_seq_serial, dim3(1), dim3(64), 0, ctx->stream, a);

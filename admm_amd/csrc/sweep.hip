@@ -179,6 +179,18 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(gw[4 * h + e]) : "v"(off_), "s"(wres) : "memory"); \
     }                                                                                                 \
   }
+  // The wait names every gathered register as read and written, so no instruction that uses one of
+  // them can be scheduled in front of it.
+#define FW_WAIT_GATHERS()                                                                             \
+  {                                                                                                   \
+    static_assert(H == 4, "operand list below is written for 16 gathered registers");                 \
+    asm volatile("s_waitcnt vmcnt(0)"                                                                 \
+                 : "+v"(gw[0]), "+v"(gw[1]), "+v"(gw[2]), "+v"(gw[3]), "+v"(gw[4]), "+v"(gw[5]), "+v"(gw[6]),    \
+                   "+v"(gw[7]), "+v"(gw[8]), "+v"(gw[9]), "+v"(gw[10]), "+v"(gw[11]), "+v"(gw[12]), "+v"(gw[13]), \
+                   "+v"(gw[14]), "+v"(gw[15])                                                         \
+                 :                                                                                    \
+                 : "memory");                                                                         \
+  }
 #define FW_PRODUCTS(PROD, HI)                                                                         \
   _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
     const uint32_t p_ = (uint32_t)(h * (4 * kFwProducers) + ptid * 4);                                \
@@ -223,7 +235,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       FW_RANGE(B, E, lo0, hi0)
       FW_ISSUE(xc, xv, B & ~3ull, E)
       FW_GATHER(lo0, hi0)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FW_WAIT_GATHERS()
       FW_PRODUCTS(prod0, hi0)
     }
     if (nmine > 1) {
@@ -286,7 +298,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         __syncthreads();
         __syncthreads();
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FW_WAIT_GATHERS()
       if (has1) {
         float *prodn = prod0 + ((i + 1) & 1) * kFwChunk;
         FW_PRODUCTS(prodn, hi1)
@@ -407,6 +419,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
 #undef FW_ISSUE
 #undef FW_GATHER
 #undef FW_PRODUCTS
+#undef FW_WAIT_GATHERS
 #undef FW_RANGE
   if (colsums) {
     // combine the waves' column sums and add them to the global accumulators
@@ -554,7 +567,7 @@ struct TArgs {
   float scale;
   uint32_t nblocks, col_block;
   uint64_t panel0, npanels;  // panels [panel0, panel0 + npanels) are swept by this launch
-  int ablate;                // development switches, 0 in normal operation
+  int no_gather;             // calibration runs only: skip the per-row gathers (results are then meaningless)
 };
 
 
@@ -633,18 +646,12 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
         vb = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.tval + k2));
       }
       float xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
-      if (a.ablate & 1) {
+      if (a.no_gather) {
         xa0 = __uint_as_float(ra.x), xa1 = __uint_as_float(ra.y), xa2 = __uint_as_float(ra.z), xa3 = __uint_as_float(ra.w);
         xb0 = __uint_as_float(rb.x), xb1 = __uint_as_float(rb.y), xb2 = __uint_as_float(rb.z), xb3 = __uint_as_float(rb.w);
       } else {
         xa0 = a.rvec[ra.x], xa1 = a.rvec[ra.y], xa2 = a.rvec[ra.z], xa3 = a.rvec[ra.w];
         xb0 = a.rvec[rb.x], xb1 = a.rvec[rb.y], xb2 = a.rvec[rb.z], xb3 = a.rvec[rb.w];
-      }
-      if (a.ablate & 2) {
-        const float sacc = xa0 * va.x + xa1 * va.y + xa2 * va.z + xa3 * va.w + xb0 * vb.x + xb1 * vb.y + xb2 * vb.z + xb3 * vb.w;
-        const uint32_t cs = (ca.x ^ ca.y ^ cb.x ^ cb.y) & 0xFFFu;
-        if (sacc == 123.456f) acc[cs] = 1;
-        continue;
       }
       t_accumulate<FTRL>(acc, acc2, bits, ca.x & 0xFFFFu, xa0, va.x, scale);
       t_accumulate<FTRL>(acc, acc2, bits, ca.x >> 16, xa1, va.y, scale);
@@ -668,7 +675,6 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
     }
   }
   __syncthreads();
-  if (a.ablate & 4) return;
   const uint64_t gbase = (uint64_t)blk * CB;
   for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
     const fx_t s = acc[c];
@@ -703,7 +709,9 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
   a.mask = csr->d_mask;
   a.nblocks = csr->nblocks;
   a.col_block = csr->col_block;
-  if (const char *ab = getenv("ADMM_ABLATE")) a.ablate = (atoi(ab) >> 8) & 0xFF;
+  // measurement aid: a gather-free run moves a known number of bytes, which calibrates the
+  // hardware counters; it computes nothing useful
+  a.no_gather = getenv("ADMM_CALIBRATE_NO_GATHER") != nullptr;
   const size_t lds = ftrl_mode ? sizeof(fx_t) * 2 * csr->col_block + sizeof(uint32_t) * (csr->col_block / 32)
                                : sizeof(fx_t) * csr->col_block;
   // more than half of the CU's LDS: one workgroup per CU, so give it the full 1024 threads

@@ -20,6 +20,6 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format cs
 echo "write done"
 # calibration of the 8-byte-per-lane stream: transposed sweep with its gathers switched off
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o pmc -- \
-  python3 "$root/tools/sweep_bench.py" --ablate 256 > "$out/calib_line.txt" 2> "$out/calib.err"
+  python3 "$root/tools/sweep_bench.py" --no-gather > "$out/calib_line.txt" 2> "$out/calib.err"
 echo "calibration done"
 find "$out" -name "*.csv" | head -20

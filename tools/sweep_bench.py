@@ -1,5 +1,6 @@
 """Development aid: time the two sweeps of one objective/gradient evaluation on a synthetic set,
-optionally with ablation switches (ADMM_ABLATE: forward bits 0-7, transposed bits 8-15)."""
+optionally with the transposed sweep's gathers switched off (--no-gather: a run that moves a
+known number of bytes, used to calibrate the hardware traffic counters)."""
 import argparse
 import os
 import sys
@@ -14,12 +15,13 @@ ap.add_argument("--draws", type=float, default=131)
 ap.add_argument("--panel-rows", type=int, default=0)
 ap.add_argument("--col-block", type=int, default=16384)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--ablate", type=str, default="0")
+ap.add_argument("--no-gather", action="store_true")
+ap.add_argument("--explicit-values", action="store_true")
 ap.add_argument("--no-relabel", action="store_true")
 args = ap.parse_args()
 
 ctx = capi.Context(0)
-s = ctx.csr_synth(args.rows, args.dim, args.draws, seed=1)
+s = ctx.csr_synth(args.rows, args.dim, args.draws, seed=1, explicit_values=args.explicit_values)
 s.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
 if not args.no_relabel:
     s.relabel_by_frequency()
@@ -30,8 +32,9 @@ rows, nnz = s.nrows, s.nnz
 print("hbm bytes: row-major %d, column-block copy %d" % s.bytes(), flush=True)
 fb = 8.0 * nnz + 16.0 * rows + 4.0 * args.dim
 tb = 8.0 * (nnz - rows) + 4.0 * rows + 4.0 * args.dim
-for ab in args.ablate.split(","):
-    os.environ["ADMM_ABLATE"] = ab
+if args.no_gather:
+    os.environ["ADMM_CALIBRATE_NO_GATHER"] = "1"
+for ab in ["no-gather" if args.no_gather else "normal"]:
     s.logistic_fg(x, g, rho=0.01)
     ctx.timing_enable(True)
     ctx.timing_reset()
@@ -40,5 +43,5 @@ for ab in args.ablate.split(","):
     f_ms, f_n = ctx.timing_get(capi.K_FORWARD)
     t_ms, t_n = ctx.timing_get(capi.K_TRANSPOSED)
     ctx.timing_enable(False)
-    print("ablate=%-6s rows=%d nnz=%d  forward %.3f ms (%.0f GB/s alg)  transposed %.3f ms (%.0f GB/s alg)"
+    print("%-9s rows=%d nnz=%d  forward %.3f ms (%.0f GB/s alg)  transposed %.3f ms (%.0f GB/s alg)"
           % (ab, rows, nnz, f_ms / f_n, fb / (f_ms / f_n) / 1e6, t_ms / t_n, tb / (t_ms / t_n) / 1e6), flush=True)
