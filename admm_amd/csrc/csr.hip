@@ -59,7 +59,7 @@ struct TBuildArgs {
   uint64_t nrows, panel_rows;
   uint32_t col_block, nblocks;
   int skip_bias;
-  int hot_dense;  // entries held by the per-row hot mask (relabelled id < 64, value 1) are left out
+  int hot_dense;  // entries held by the per-row masks (relabelled id < kMaskCols, value 1) are left out
   unsigned long long *cell_count;   // pass 1: entries per cell
   unsigned long long *cell_cursor;  // pass 2: next free slot per cell (starts at tptr[cell])
   uint32_t *trow;
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
     const uint64_t kb = a.rowptr[r0], ke = a.rowptr[r1];
     for (uint64_t k = kb + threadIdx.x; k < ke; k += 256) {
       uint32_t c = a.col[k];
-      if (a.hot_dense && c < 64u && (!a.val || a.val[k] == 1.0f)) continue;
+      if (a.hot_dense && c < kMaskCols && (!a.val || a.val[k] == 1.0f)) continue;
       if (a.perm) c = a.perm[c];
       if (a.skip_bias && c == 0) continue;
       atomicAdd(&cnt[c / a.col_block], 1u);
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
         const uint64_t b = a.rowptr[r], e = a.rowptr[r + 1];
         for (uint64_t k = b + sub; k < e; k += 16) {
           uint32_t c = a.col[k];
-          if (a.hot_dense && c < 64u && (!a.val || a.val[k] == 1.0f)) continue;
+          if (a.hot_dense && c < kMaskCols && (!a.val || a.val[k] == 1.0f)) continue;
           if (a.perm) c = a.perm[c];
           if (a.skip_bias && c == 0) continue;
           const uint32_t blk = c / a.col_block;
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ ro
                                                  uint64_t *__restrict__ rowlen,
                                                  const uint64_t *__restrict__ crowptr,
                                                  uint32_t *__restrict__ ccol, float *__restrict__ cval,
-                                                 uint64_t *__restrict__ hmask) {
+                                                 uint64_t *__restrict__ hmask, uint64_t *__restrict__ hwarm) {
   // one 16-lane group per row
   const int lane = threadIdx.x & 63, sub = threadIdx.x & 15, gshift = lane & 48;
   const uint64_t grp = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ ro
     const bool live = r < nrows;
     const uint64_t b = live ? rowptr[r] : 0, e = live ? rowptr[r + 1] : 0;
     uint64_t out = FILL && live ? crowptr[r] : 0;
-    uint32_t mlo = 0, mhi = 0, ncold = 0;
+    uint32_t mbits[2 * (1 + kWarmWords)] = {};
+    uint32_t ncold = 0;
     const uint64_t trips = (e - b + 15) / 16;
     uint64_t maxtrips = trips;
     for (int off = 32; off > 0; off >>= 1) {
@@ -340,11 +341,12 @@ __global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ ro
       const bool have = live && k < e;
       const uint32_t c = have ? col[k] : 0xFFFFFFFFu;
       const float v = have ? (val ? val[k] : 1.0f) : 0.0f;
-      const bool hot = have && c < 64u && v == 1.0f;
+      const bool hot = have && c < kMaskCols && v == 1.0f;
       const bool cold = have && !hot;
       if (hot) {
-        if (c < 32u) mlo |= 1u << c;
-        else mhi |= 1u << (c - 32u);
+#pragma unroll
+        for (int w = 0; w < 2 * (1 + kWarmWords); ++w)
+          if ((c >> 5) == (uint32_t)w) mbits[w] |= 1u << (c & 31u);
       }
       const unsigned long long cm = __ballot(cold);
       const uint32_t gm = (uint32_t)((cm >> gshift) & 0xFFFFu);
@@ -358,12 +360,15 @@ __global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ ro
     }
     if (!FILL) {
       for (int off = 8; off > 0; off >>= 1) {
-        mlo |= __shfl_xor(mlo, off, 64);
-        mhi |= __shfl_xor(mhi, off, 64);
+#pragma unroll
+        for (int w = 0; w < 2 * (1 + kWarmWords); ++w) mbits[w] |= __shfl_xor(mbits[w], off, 64);
       }
       if (live && sub == 0) {
         rowlen[r] = ncold;
-        hmask[r] = ((uint64_t)mhi << 32) | mlo;
+        hmask[r] = ((uint64_t)mbits[1] << 32) | mbits[0];
+#pragma unroll
+        for (int w = 0; w < kWarmWords; ++w)
+          hwarm[r * kWarmWords + w] = ((uint64_t)mbits[2 * w + 3] << 32) | mbits[2 * w + 2];
       }
     }
   }
@@ -402,7 +407,7 @@ static void free_csr(admm_csr *c) {
   }
   void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_tptr,
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask,
-                  c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol};
+                  c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;
@@ -608,17 +613,18 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
   cleanup();
   count = count_sorted = ids = nullptr;
   tmp = nullptr;
-  // compact form for the forward sweep (sets whose rows never repeat a column, dim >= 64)
-  if (!csr->has_dup_cols && dim >= 64 && csr->nrows > 0) {
+  // compact form for the forward sweep (sets whose rows never repeat a column, dim >= kMaskCols)
+  if (!csr->has_dup_cols && dim >= kMaskCols && csr->nrows > 0) {
     const uint64_t n = csr->nrows;
     uint64_t *rowlen = nullptr;
     RL_CHECK(hipMalloc(&rowlen, sizeof(uint64_t) * (n + 1)));
     RL_CHECK(hipMemsetAsync(rowlen, 0, sizeof(uint64_t) * (n + 1), ctx->stream));
     RL_CHECK(hipMalloc(&csr->d_hmask, sizeof(uint64_t) * n));
+    RL_CHECK(hipMalloc(&csr->d_hwarm, sizeof(uint64_t) * n * kWarmWords));
     RL_CHECK(hipMalloc(&csr->d_crowptr, sizeof(uint64_t) * (n + 1)));
     const int cgrid = grid_for(n * 16, 256, ctx->cu_count * 8);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact<false>), dim3(cgrid), dim3(256), 0, ctx->stream, csr->d_rowptr,
-                       csr->d_col, csr->d_val, n, rowlen, nullptr, nullptr, nullptr, csr->d_hmask);
+                       csr->d_col, csr->d_val, n, rowlen, nullptr, nullptr, nullptr, csr->d_hmask, csr->d_hwarm);
     size_t sbytes = 0;
     hipError_t se = hipcub::DeviceScan::ExclusiveSum(nullptr, sbytes, rowlen, csr->d_crowptr, (int64_t)(n + 1), ctx->stream);
     void *stmp = nullptr;
@@ -636,7 +642,7 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
     RL_CHECK(hipMalloc(&csr->d_ccol, sizeof(uint32_t) * (total + 8)));
     if (csr->d_val) RL_CHECK(hipMalloc(&csr->d_cval, sizeof(float) * (total + 8)));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact<true>), dim3(cgrid), dim3(256), 0, ctx->stream, csr->d_rowptr,
-                       csr->d_col, csr->d_val, n, nullptr, csr->d_crowptr, csr->d_ccol, csr->d_cval, nullptr);
+                       csr->d_col, csr->d_val, n, nullptr, csr->d_crowptr, csr->d_ccol, csr->d_cval, nullptr, nullptr);
     RL_CHECK(hipGetLastError());
     RL_CHECK(hipStreamSynchronize(ctx->stream));
     csr->hot_dense = true;

@@ -40,6 +40,12 @@ void set_error(const char *fmt, ...);
     if (rc_ != ADMM_OK) return rc_; \
   } while (0)
 
+// Relabelled sets keep their unit-valued entries in the most frequent columns as bits per row:
+// one 64-bit word for columns 0..63 (`hmask`) and kWarmWords more for the columns after them
+// (`hwarm`, row-major).  Those entries are stored nowhere else.
+constexpr int kWarmWords = 3;
+constexpr uint32_t kMaskCols = 64u * (1 + kWarmWords);
+
 constexpr int kMaxPartialBlocks = 4096;  // reduction partial slots per output scalar
 constexpr int kPartialScalars = 8;       // scalars a reducing kernel may emit
 
@@ -90,7 +96,7 @@ struct admm_csr {
   // compact row-major form used by the forward sweep of a relabelled set: per row a 64-bit mask of
   // its unit-valued entries in the 64 most frequent columns, and the remaining entries as CSR
   bool hot_dense = false;
-  uint64_t *d_hmask = nullptr, *d_crowptr = nullptr;
+  uint64_t *d_hmask = nullptr, *d_hwarm = nullptr, *d_crowptr = nullptr;
   uint32_t *d_ccol = nullptr;
   float *d_cval = nullptr;
   uint64_t cnnz = 0;

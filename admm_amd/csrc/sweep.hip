@@ -33,6 +33,7 @@ struct FwdArgs {
   // compact sets: per-row mask of unit entries in columns 0..63 (nullptr otherwise), and where the
   // per-column sums of those columns go (64-bit fixed point accumulators indexed by original id)
   const uint64_t *hmask;
+  const uint64_t *hwarm;  // kWarmWords more mask words per row (columns 64 .. kMaskCols-1)
   const uint32_t *perm;
   unsigned long long *g1, *g2;
   uint32_t *gmask;
@@ -57,9 +58,9 @@ constexpr int kFwChunk = 8192;
 constexpr int kFwHot = 16384;
 constexpr int kFwLanesPerRow = kFwConsumers / kFwRowSlots;  // 2
 constexpr int kFwSlots = 4;                                  // tiles whose row data is resident in LDS
-constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 2) * kFwRowSlots) +
+constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 1) * kFwRowSlots) +
                           sizeof(unsigned long long) * (kFwSlots * (kFwRowSlots + 2) + kFwSlots * kFwRowSlots +
-                                                        2 * kFwRowSlots) + 64;
+                                                        2 * kFwRowSlots * kWarmWords + 2 * 64 * kWarmWords + kWarmWords) + 64;
 
 // CSR-stream forward sweep.  The stored entries of a tile's rows are one contiguous range of
 // col/val.  Producer threads stream it with 16-byte loads (four entries per lane per load),
@@ -87,14 +88,15 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   extern __shared__ unsigned long long fw_lds[];
   unsigned long long *rp0 = fw_lds;                                     // [kFwSlots][kFwRowSlots + 2] row pointers
   unsigned long long *mask0 = rp0 + kFwSlots * (kFwRowSlots + 2);       // [kFwSlots][kFwRowSlots] hot masks
-  unsigned long long *rfx_s = mask0 + kFwSlots * kFwRowSlots;           // [kFwRowSlots] residual, fixed point
-  unsigned long long *rfx2_s = rfx_s + kFwRowSlots;                     // [kFwRowSlots] its square (FTRL form)
-  float *prod0 = reinterpret_cast<float *>(rfx2_s + kFwRowSlots);       // [2][kFwChunk]
+  unsigned long long *warm0 = mask0 + kFwSlots * kFwRowSlots;           // [2][kFwRowSlots][kWarmWords] warm masks
+  unsigned long long *wacc = warm0 + 2 * kFwRowSlots * kWarmWords;      // [64 * kWarmWords] X^T r of the warm columns
+  unsigned long long *wacc2 = wacc + 64 * kWarmWords;                   // [64 * kWarmWords] same for r^2 (FTRL form)
+  unsigned long long *wseen = wacc2 + 64 * kWarmWords;                  // [kWarmWords] warm columns seen (FTRL form)
+  float *prod0 = reinterpret_cast<float *>(wseen + kWarmWords);         // [2][kFwChunk]
   float *hot = prod0 + 2 * kFwChunk;                                    // [kFwHot]
   float *tab = hot + kFwHot;                                            // [8][256] byte -> sum of hot weights
   float *lab0 = tab + 8 * 256;                                          // [kFwSlots][kFwRowSlots] labels
-  float *msum = lab0 + kFwSlots * kFwRowSlots;                          // [kFwRowSlots] margins of the tile
-  float *out_s = msum + kFwRowSlots;                                    // [kFwRowSlots] per-row results of the tile
+  float *out_s = lab0 + kFwSlots * kFwRowSlots;                         // [kFwRowSlots] per-row results of the tile
   __shared__ double shred[kFwThreads / 64];
   // after the tile loop the product buffer is free: per-wave column sums are combined there
   unsigned long long(*hsum)[64] = reinterpret_cast<unsigned long long(*)[64]>(prod0);
@@ -113,6 +115,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   const bool hasval = a.val != nullptr;
   const bool colsums = dense && MODE != FWD_EVAL;  // X^T r of the mask columns is wanted
   for (uint32_t j = tid; j < nhot; j += kFwThreads) hot[j] = wsum[j];
+  if (tid < 2 * 64 * kWarmWords + kWarmWords) wacc[tid] = 0ull;  // wacc, wacc2, wseen are contiguous
   if (dense) {
     // tab[g][byte] = sum of the weights of columns 8g .. 8g+7 selected by the bits of `byte`
     __syncthreads();
@@ -228,6 +231,10 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       lab0[slot * kFwRowSlots + tid] = tid < nr ? a.label[rb + tid] : 0.0f;
     }
   }
+  if (dense && nmine > 0) {
+    const int nr = tile_rows(tile_of(0));
+    if (tid < nr * kWarmWords) warm0[tid] = a.hwarm[(a.r0 + tile_of(0) * rpt) * kWarmWords + tid];
+  }
   __syncthreads();  // also orders the fill of hot[] / tab[] before their first use
   if (producer) {
     if (nmine > 0) {
@@ -287,6 +294,10 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         else if (dense && ptid > kFwRowSlots && ptid - (kFwRowSlots + 1) < nr3) pf = a.hmask[rb3 + ptid - (kFwRowSlots + 1)];
         if (ptid < nr3) pf_lab = a.label[rb3 + ptid];
       }
+      // warm mask words of the next tile (needed by the consumers one iteration from now)
+      unsigned long long pf_warm = 0;
+      const int nw1 = (dense && has1) ? tile_rows(tile_of(i + 1)) * kWarmWords : 0;
+      if (ptid < nw1) pf_warm = a.hwarm[(a.r0 + tile_of(i + 1) * rpt) * kWarmWords + ptid];
       if (has1) {
         const unsigned long long *rp1 = rp0 + slot1 * (kFwRowSlots + 2);
         const unsigned long long B1 = rp1[0], E1 = rp1[tile_rows(tile_of(i + 1))];
@@ -308,6 +319,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         else if (ptid > kFwRowSlots && ptid <= 2 * kFwRowSlots) mask0[slot3 * kFwRowSlots + ptid - (kFwRowSlots + 1)] = pf;
         if (ptid < kFwRowSlots) lab0[slot3 * kFwRowSlots + ptid] = pf_lab;
       }
+      if (ptid < nw1) warm0[((i + 1) & 1) * kFwRowSlots * kWarmWords + ptid] = pf_warm;
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         xc[h] = yc[h];
@@ -354,6 +366,24 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         for (int b8 = 0; b8 < kBytesPerLane; ++b8) {
           const int g = q * kBytesPerLane + b8;
           rowsum += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
+        }
+      }
+      // warm columns: the row's two lanes take the even and the odd bits of its warm words and walk
+      // their set bits, two LDS reads per trip
+      static_assert(kFwLanesPerRow == 2, "even / odd bit split");
+      unsigned long long my_w[kWarmWords];
+#pragma unroll
+      for (int w = 0; w < kWarmWords; ++w) {
+        const unsigned long long half = q ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+        my_w[w] = (dense && trow < nr) ? (warm0[((i & 1) * kFwRowSlots + trow) * kWarmWords + w] & half) : 0ull;
+        unsigned long long m = my_w[w];
+        while (m) {
+          const float v0 = hot[64 * (w + 1) + __builtin_ctzll(m)];
+          m &= m - 1;
+          const float v1 = m ? hot[64 * (w + 1) + __builtin_ctzll(m)] : 0.0f;
+          m &= m - 1;
+          rowsum += v0;
+          rowsum += v1;
         }
       }
 #pragma unroll
@@ -408,6 +438,18 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
             hseen |= m;
           }
         }
+        // warm columns: few set bits per row, added to per-column LDS accumulators
+        const unsigned long long rrow = __shfl(my_r, lane & ~(kFwLanesPerRow - 1), 64);
+        const unsigned long long rrow2 = MODE == FWD_FTRL ? __shfl(my_r2, lane & ~(kFwLanesPerRow - 1), 64) : 0ull;
+#pragma unroll
+        for (int w = 0; w < kWarmWords; ++w) {
+          for (unsigned long long m = my_w[w]; m; m &= m - 1) {
+            const int c = 64 * w + __builtin_ctzll(m);
+            atomicAdd(&wacc[c], rrow);
+            if (MODE == FWD_FTRL) atomicAdd(&wacc2[c], rrow2);
+          }
+          if (MODE == FWD_FTRL && my_w[w]) atomicOr(&wseen[w], my_w[w]);
+        }
       }
     }
     __syncthreads();
@@ -422,6 +464,15 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
 #undef FW_WAIT_GATHERS
 #undef FW_RANGE
   if (colsums) {
+    __syncthreads();
+    if (tid < 64 * kWarmWords) {
+      const uint32_t o = a.perm[64 + tid];
+      if (wacc[tid]) atomicAdd(a.g1 + o, wacc[tid]);
+      if (MODE == FWD_FTRL) {
+        if (wacc2[tid]) atomicAdd(a.g2 + o, wacc2[tid]);
+        if ((wseen[tid >> 6] >> (tid & 63)) & 1ull) atomicOr(&a.gmask[o >> 5], 1u << (o & 31));
+      }
+    }
     // combine the waves' column sums and add them to the global accumulators
     for (int pass = 0; pass < (MODE == FWD_FTRL ? 2 : 1); ++pass) {
       __syncthreads();
@@ -505,6 +556,7 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.label = csr->d_label;
   if (csr->hot_dense) {
     a.hmask = csr->d_hmask;
+    a.hwarm = csr->d_hwarm;
     a.perm = csr->d_perm;
     if (mode != FWD_EVAL) {
       ADMM_REQUIRE(csr->has_t, "forward sweep: the training forms need admm_csr_build_transposed");
