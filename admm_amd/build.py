@@ -46,7 +46,7 @@ def build_lib(verbose=False):
 
 
 HOST_SOURCES = ["runtime.cc", "arg_parser.cc", "sample_set.cc", "solvers.cc", "model_io.cc"]
-HOST_MAINS = {"admm": "admm_main.cc", "ftrl": "ftrl_main.cc", "evan": "eval_main.cc"}
+HOST_MAINS = {"admm": "admm_main.cc", "ftrl": "ftrl_main.cc", "evan": "eval_main.cc", "parsecheck": "parse_main.cc"}
 
 
 def build_host(verbose=False):
@@ -54,7 +54,7 @@ def build_host(verbose=False):
     bindir = os.path.join(PKG, "bin")
     os.makedirs(bindir, exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
-    flags = ["-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", HOST]
+    flags = ["-O2", "-std=c++17", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", HOST]
     srcs = [os.path.join(HOST, s) for s in HOST_SOURCES if os.path.exists(os.path.join(HOST, s))]
     outs = []
     for name, main in HOST_MAINS.items():

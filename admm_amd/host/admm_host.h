@@ -152,6 +152,13 @@ class SampleSet {
   // indices shifted by one, src/sample_set.cc:70-88) into HBM.  dim = 0 sizes the set by its
   // largest index.  Returns false when the file cannot be opened.
   bool Initialize(const std::string &uri, uint32_t part_index, uint32_t num_parts, size_t dim = 0);
+  // The host half of Initialize: part `part_index` of `num_parts` of a libsvm text file as CSR
+  // arrays without the bias column (several threads; ADMM_PARSE_THREADS, default min(cores, 16)).
+  // With ADMM_CSR_CACHE_DIR set the arrays are also kept there as a binary file that later runs
+  // read instead of parsing, for as long as the text file's size and modification time match.
+  static bool ParseText(const std::string &uri, uint32_t part_index, uint32_t num_parts,
+                        std::vector<uint64_t> &rowptr, std::vector<uint32_t> &col, std::vector<float> &val,
+                        std::vector<float> &label, uint32_t *max_index);
   bool Next();
   Row GetData();
   void Rewind();

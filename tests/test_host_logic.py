@@ -56,3 +56,77 @@ def test_shard_ranges_partition_the_rows():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _parsecheck(path, part, nparts, env=None):
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "admm_amd", "bin", "parsecheck")
+    if not os.path.exists(exe):
+        from admm_amd import build
+        build.build_lib()
+        build.build_host()
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([exe, str(path), str(part), str(nparts)], capture_output=True, text=True, timeout=60, env=e)
+    assert out.returncode == 0, out.stderr
+    return out.stdout
+
+
+def _expected_dump(csr):
+    lines = ["%d %d %d" % (csr.nrows, csr.nnz, int(csr.col.max()) if csr.nnz else 0)]
+    for r in range(csr.nrows):
+        b, e = int(csr.rowptr[r]), int(csr.rowptr[r + 1])
+        lines.append(" ".join(["%.9g" % csr.label[r]] +
+                              ["%d:%.9g" % (int(csr.col[k]), float(csr.val[k])) for k in range(b, e)]))
+    return "\n".join(lines) + "\n"
+
+
+def test_threaded_libsvm_loader_matches_the_oracle_reader(tmp_path, oracle):
+    """the C++ loader (several threads, byte-range parts, the float fast path, the binary cache)
+    against the oracle's reading of the same text"""
+    rng = np.random.default_rng(5)
+    path = tmp_path / "part-00000"
+    with open(path, "w") as f:
+        for r in range(3000):
+            n = int(rng.integers(0, 30))
+            ids = np.sort(rng.choice(5000, n, replace=False))
+            toks = []
+            for i in ids:
+                kind = rng.integers(0, 5)
+                if kind == 0:
+                    toks.append("%d" % i)                       # index alone: value 1
+                elif kind == 1:
+                    toks.append("%d:1" % i)
+                elif kind == 2:
+                    toks.append("%d:%.4f" % (i, rng.uniform(-3, 3)))
+                elif kind == 3:
+                    toks.append("%d:%.9g" % (i, rng.normal()))   # long mantissa -> strtof
+                else:
+                    toks.append("%d:%.3e" % (i, rng.normal()))   # exponent -> strtof
+            f.write("%s %s%s\n" % (rng.choice(["1", "0", "-1", "+1", "0.5"]), " ".join(toks),
+                                   "\r" if r % 7 == 0 else ""))
+            if r % 500 == 499:
+                f.write("\n")                                    # blank lines are skipped
+    text = open(path, "rb").read()
+    for nparts in (1, 3):
+        for part in range(nparts):
+            want = _expected_dump(oracle.parse_libsvm_text(text, part, nparts))
+            for threads in ("1", "5"):
+                got = _parsecheck(path, part, nparts, {"ADMM_PARSE_THREADS": threads, "ADMM_PARSE_MIN_BYTES": "4096"})
+                assert got == want
+    # the binary cache: written by the first run, read by the second, dropped when the text changes
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = {"ADMM_CSR_CACHE_DIR": str(cache)}
+    want = _expected_dump(oracle.parse_libsvm_text(text, 1, 3))
+    assert _parsecheck(path, 1, 3, env) == want
+    files = list(cache.iterdir())
+    assert len(files) == 1
+    stamp = files[0].stat().st_mtime_ns
+    assert _parsecheck(path, 1, 3, env) == want and files[0].stat().st_mtime_ns == stamp
+    with open(path, "a") as f:
+        f.write("1 7:2.5\n")
+    text2 = open(path, "rb").read()
+    assert _parsecheck(path, 2, 3, env) == _expected_dump(oracle.parse_libsvm_text(text2, 2, 3))
+    assert _parsecheck(path, 1, 3, env) == _expected_dump(oracle.parse_libsvm_text(text2, 1, 3))
