@@ -20,7 +20,7 @@ SYMBOLS = [
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
     "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_destroy",
-    "admm_predict", "admm_metrics", "admm_ftrl_pass", "admm_logistic_fg", "admm_lbfgs_solve",
+    "admm_predict", "admm_metrics", "admm_ftrl_pass", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus",
     "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32",
 ]
@@ -90,6 +90,7 @@ def load():
         "admm_metrics": [vp, C.POINTER(vp), i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                          C.POINTER(u64)],
         "admm_ftrl_pass": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, u64],
+        "admm_ftrl_pass_multi": [vp, vp, vp, vp, vp, vp, C.c_int, f32, f32, f32, f32],
         "admm_logistic_fg": [vp, vp, vp, vp, vp, f32, C.POINTER(C.c_double), vp],
         "admm_lbfgs_solve": [vp, vp, vp, vp, vp, f32, C.POINTER(LbfgsParams),
                              C.POINTER(LbfgsResult)],
@@ -219,6 +220,16 @@ class Context:
         h = C.c_void_p()
         _check(self.L.admm_csr_synth(self.h, C.byref(spec), C.byref(h)))
         return SampleSet(self, h)
+
+    def ftrl_pass_multi(self, sets, w, z, n, offset, reg_offset, alpha, beta, l_1, l_2):
+        """admm_ftrl_pass_multi: pass k runs sets[k] with state w[k], z[k], n[k]"""
+        cnt = len(sets)
+        assert all(len(v) == cnt for v in (w, z, n, offset, reg_offset))
+        def arr(items, get):
+            return (C.c_void_p * cnt)(*[getattr(get(i), "value", get(i)) for i in items])
+        _check(self.L.admm_ftrl_pass_multi(arr(sets, lambda s: s.h), arr(w, lambda v: v.ptr), arr(z, lambda v: v.ptr),
+                                           arr(n, lambda v: v.ptr), arr(offset, lambda v: v.ptr),
+                                           arr(reg_offset, lambda v: v.ptr), cnt, alpha, beta, l_1, l_2))
 
     # consensus algebra --------------------------------------------------------------------
     def payload(self, x, ydual, rho, out):

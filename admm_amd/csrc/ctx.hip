@@ -294,6 +294,7 @@ extern "C" int admm_ctx_destroy(admm_ctx *ctx) {
   if (ctx->d_scalars) hipFree(ctx->d_scalars);
   if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
   if (ctx->lbfgs_ws) hipFree(ctx->lbfgs_ws);
+  if (ctx->d_multi) hipFree(ctx->d_multi);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return ADMM_OK;

@@ -222,8 +222,8 @@ constexpr int kStatic = 8;     // column ids / values / dependences are fetched 
 // compiler at the top of the loop, which then waits for ALL of them and so undoes the look-ahead.
 // EPL = stored entries per lane: rows of up to 64 * EPL entries
 template <int EPL, bool HASVAL>
-__global__ void __launch_bounds__(64)
-    k_ftrl_seq_ring(SeqArgs a, const uint32_t *__restrict__ col, const uint32_t *__restrict__ dep, uint64_t nnz) {
+__device__ __forceinline__ void ftrl_ring_body(const SeqArgs &a, const uint32_t *__restrict__ col,
+                                               const uint32_t *__restrict__ dep, uint64_t nnz) {
   __shared__ float ring_z_[kRing][64 * EPL];
   __shared__ float ring_n_[kRing][64 * EPL];
   // plain (not volatile) LDS accesses: a wavefront's LDS operations execute in order, and a
@@ -350,6 +350,33 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+template <int EPL, bool HASVAL>
+__global__ void __launch_bounds__(64)
+    k_ftrl_seq_ring(SeqArgs a, const uint32_t *__restrict__ col, const uint32_t *__restrict__ dep, uint64_t nnz) {
+  ftrl_ring_body<EPL, HASVAL>(a, col, dep, nnz);
+}
+
+// Many independent passes in one launch, one single-wave workgroup each: the reference runs one
+// worker per process (and per core); on the GPU the workers of a job are resident together and
+// their passes run side by side.
+struct MultiEntry {
+  SeqArgs a;
+  const uint32_t *col, *dep;
+  uint64_t nnz;
+  int epl, hasval;
+};
+
+__global__ void __launch_bounds__(64) k_ftrl_seq_multi(const MultiEntry *__restrict__ entries) {
+  const MultiEntry m = entries[blockIdx.x];
+  if (m.epl == 1) {
+    if (m.hasval) ftrl_ring_body<1, true>(m.a, m.col, m.dep, m.nnz);
+    else ftrl_ring_body<1, false>(m.a, m.col, m.dep, m.nnz);
+  } else {
+    if (m.hasval) ftrl_ring_body<2, true>(m.a, m.col, m.dep, m.nnz);
+    else ftrl_ring_body<2, false>(m.a, m.col, m.dep, m.nnz);
+  }
+}
+
 // (rows_back << 16) | position for every stored entry, computed on the host from the device CSR
 static int ensure_dep(admm_csr *csr) {
   if (csr->d_dep) return ADMM_OK;
@@ -427,6 +454,68 @@ int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const floa
   else
     hipLaunchKernelGGL(k_ftrl_seq, dim3(1), dim3(64), 0, ctx->stream, a);
   ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
+int ftrl_pass_multi(admm_csr *const *sets, float *const *w, float *const *z, float *const *n,
+                    const float *const *offset, const float *const *reg_offset, int count, float alpha, float beta,
+                    float l1, float l2) {
+  if (count <= 0) return ADMM_OK;
+  admm_ctx *ctx = sets[0]->ctx;
+  std::vector<MultiEntry> entries;
+  std::vector<int> single;  // sets the pipelined kernel does not take: repeated columns, very long rows
+  for (int k = 0; k < count; ++k) {
+    admm_csr *csr = sets[k];
+    ADMM_REQUIRE(csr->ctx == ctx, "admm_ftrl_pass_multi: sample set %d belongs to another context", k);
+    if (csr->nrows == 0) continue;
+    if (!csr->has_dup_cols) ADMM_TRY(ensure_dep(csr));
+    if (csr->has_dup_cols || !csr->d_dep || csr->nnz == 0 || csr->max_row_len > 128) {
+      single.push_back(k);
+      continue;
+    }
+    MultiEntry m{};
+    m.a.rowptr = csr->d_rowptr;
+    m.a.col = csr->d_col;
+    m.a.perm = csr->d_perm;
+    m.a.val = csr->d_val;
+    m.a.label = csr->d_label;
+    m.a.nrows = csr->nrows;
+    m.a.w = w[k];
+    m.a.z = z[k];
+    m.a.n = n[k];
+    m.a.offset = offset[k];
+    m.a.reg = reg_offset[k];
+    m.a.alpha = alpha;
+    m.a.beta = beta;
+    m.a.l1 = l1;
+    m.a.l2 = l2;
+    m.col = csr->d_seqcol ? csr->d_seqcol : csr->d_col;
+    m.dep = csr->d_dep;
+    m.nnz = csr->nnz;
+    m.epl = csr->max_row_len > 64 ? 2 : 1;
+    m.hasval = csr->d_val != nullptr;
+    entries.push_back(m);
+  }
+  if (!entries.empty()) {
+    const size_t bytes = sizeof(MultiEntry) * entries.size();
+    if (ctx->multi_bytes < bytes) {
+      ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // an earlier launch may still read the old buffer
+      if (ctx->d_multi) hipFree(ctx->d_multi);
+      ctx->d_multi = nullptr;
+      ctx->multi_bytes = 0;
+      ADMM_HIP_CHECK(hipMalloc(&ctx->d_multi, bytes));
+      ctx->multi_bytes = bytes;
+    }
+    // stream-ordered: an earlier launch on this stream has finished with the buffer before the copy
+    ADMM_HIP_CHECK(hipMemcpyAsync(ctx->d_multi, entries.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // `entries` is pageable host memory
+    KernelTimer t(ctx, ADMM_K_FTRL_SEQ);
+    hipLaunchKernelGGL(k_ftrl_seq_multi, dim3((unsigned)entries.size()), dim3(64), 0, ctx->stream,
+                       static_cast<const MultiEntry *>(ctx->d_multi));
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  for (int k : single)
+    ADMM_TRY(ftrl_pass_sequential(sets[k], w[k], z[k], n[k], offset[k], reg_offset[k], alpha, beta, l1, l2));
   return ADMM_OK;
 }
 

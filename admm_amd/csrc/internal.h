@@ -75,6 +75,9 @@ struct admm_ctx {
   // L-BFGS workspace (lazily sized)
   float *lbfgs_ws = nullptr;
   uint64_t lbfgs_ws_floats = 0;
+  // argument table of a multi-pass FTRL launch
+  void *d_multi = nullptr;
+  size_t multi_bytes = 0;
   // RCCL
   void *comm = nullptr;
   int rank = 0, world = 1;

@@ -1166,6 +1166,25 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
 namespace admm_impl {
 int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,
                          float alpha, float beta, float l1, float l2);  // ftrl.hip
+int ftrl_pass_multi(admm_csr *const *sets, float *const *w, float *const *z, float *const *n,
+                    const float *const *offset, const float *const *reg_offset, int count, float alpha, float beta,
+                    float l1, float l2);  // ftrl.hip
+}
+
+extern "C" int admm_ftrl_pass_multi(admm_csr *const *sets, float *const *w, float *const *z, float *const *n,
+                                    const float *const *offset, const float *const *reg_offset, int count,
+                                    float alpha, float beta, float l1, float l2) {
+  ADMM_REQUIRE(count >= 0, "admm_ftrl_pass_multi: negative count");
+  ADMM_REQUIRE(count == 0 || (sets && w && z && n && offset && reg_offset), "admm_ftrl_pass_multi: NULL argument");
+  ADMM_REQUIRE(alpha > 0, "admm_ftrl_pass_multi: alpha must be > 0");
+  for (int k = 0; k < count; ++k) {
+    ADMM_REQUIRE(sets[k] && w[k] && z[k] && n[k] && offset[k] && reg_offset[k],
+                 "admm_ftrl_pass_multi: NULL argument for pass %d", k);
+    for (int j = 0; j < k; ++j)
+      ADMM_REQUIRE(w[j] != w[k] && z[j] != z[k] && n[j] != n[k],
+                   "admm_ftrl_pass_multi: passes %d and %d share a state vector", j, k);
+  }
+  return ftrl_pass_multi(sets, w, z, n, offset, reg_offset, count, alpha, beta, l1, l2);
 }
 
 extern "C" int admm_ftrl_pass(admm_csr *csr, float *w, float *z, float *n, const float *offset,

@@ -182,6 +182,30 @@ class Worker:
         self.ctx.payload(self.base_vec_, self.langr_vec_, admm_params.step_size, out)
 
 
+def base_update_multi(workers, parts_of, admm_params, global_weights):
+    """Worker.BaseUpdate (FTRL local solver, row-by-row passes) of several workers that live on one
+    GPU, with the workers' passes over their k-th parts launched together.  parts_of[i] lists
+    worker i's data parts.  Every worker ends in exactly the state its own BaseUpdate gives."""
+    assert admm_params.local_solver == "ftrl" and admm_params.ftrl_batch == 1
+    ctx = workers[0].ctx
+    for wk in workers:
+        wk.base_vec_.zero()
+        wk._n.copy_from(wk.nt_vec_)
+        wk._z.copy_from(wk.zt_vec_)
+    for k in range(max(len(p) for p in parts_of)):
+        idx = [i for i, p in enumerate(parts_of) if k < len(p)]
+        ctx.ftrl_pass_multi([parts_of[i][k] for i in idx], [workers[i].base_vec_ for i in idx],
+                            [workers[i]._z for i in idx], [workers[i]._n for i in idx],
+                            [workers[i].bias_vec_ for i in idx], [global_weights] * len(idx),
+                            admm_params.ftrl_alpha, 1.0, 1.0, 200.0)
+    for wk in workers:
+        if wk.load:
+            wk.nt_vec_.copy_from(wk._n)
+            wk.zt_vec_.copy_from(wk._z)
+            wk.load = False
+    return dict(evals=sum(len(p) for p in parts_of))
+
+
 class Master:
     """src/master.h:12-17"""
 

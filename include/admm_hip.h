@@ -144,6 +144,16 @@ int admm_ftrl_pass(admm_csr *csr, float *w, float *z, float *n, const float *off
                    const float *reg_offset, float alpha, float beta, float l1, float l2,
                    uint64_t batch);
 
+/* `count` independent sequential passes (admm_ftrl_pass with batch == 1) in one launch: pass k
+ * runs sample set sets[k] with its own state w[k], z[k], n[k] and its own offset[k] /
+ * reg_offset[k] (which may be shared between passes; the state vectors may not).  This is
+ * Worker::BaseUpdate (src/workers.cc:51-87) of many workers at once: the reference runs one
+ * worker per process, a GPU holds the shards of hundreds and runs their passes side by side, one
+ * wavefront each.  Every pass gives exactly the result of its own admm_ftrl_pass call. */
+int admm_ftrl_pass_multi(admm_csr *const *sets, float *const *w, float *const *z, float *const *n,
+                         const float *const *offset, const float *const *reg_offset, int count,
+                         float alpha, float beta, float l1, float l2);
+
 /* ---- batch local objective for the L-BFGS local solver (no counterpart in the reference; the
  *      x-update of src/workers.cc:51-87 solved as a smooth problem) ------------------------- */
 

@@ -16,7 +16,7 @@ def ctx():
     c.close()
 
 
-def _run_gpu(ctx, raws_train, raws_test, conf, dim):
+def _run_gpu(ctx, raws_train, raws_test, conf, dim, multi=False):
     from admm_amd import driver
     nrank = len(raws_train)
     prm = driver.AdmmConfig()
@@ -47,7 +47,12 @@ def _run_gpu(ctx, raws_train, raws_test, conf, dim):
         for r in range(nrank):
             if last:
                 workers[r].load = True
-            stats.append(workers[r].BaseUpdate(trains[r], prm, zs[r]))
+        if multi:   # the workers share the GPU: their row-by-row passes go out as one launch
+            st = driver.base_update_multi(workers, trains, prm, zs[0])
+            stats = [dict(evals=st["evals"] // nrank)] * nrank
+        for r in range(nrank):
+            if not multi:
+                stats.append(workers[r].BaseUpdate(trains[r], prm, zs[r]))
             workers[r].GetWeights(prm, tmps[r])
         # the all-reduce: host sum in rank order, as the oracle does
         total = np.zeros(dim, np.float32)
@@ -89,15 +94,15 @@ def _compare(rec_gpu, rec_ref, rtol, atol, line_rel=2e-5, auc_rel=5e-5, res_rel=
             assert s2a == pytest.approx(s2b, rel=res_rel, abs=1e-14)
 
 
-@pytest.mark.parametrize("nrank", [1, 3])
-def test_admm_ftrl_mode_matches_reference_loop(ctx, oracle, nrank):
+@pytest.mark.parametrize("nrank,multi", [(1, False), (3, False), (3, True)])
+def test_admm_ftrl_mode_matches_reference_loop(ctx, oracle, nrank, multi):
     dim = 257
     raws_train = [make_synth_csr(1200, dim, 14, seed=50 + r) for r in range(nrank)]
     raws_test = [make_synth_csr(300, dim, 14, seed=60 + r) for r in range(nrank)]
     conf = oracle.AdmmConf(step_size=0.01, global_var=4.0, ftrl_alpha=0.1, passes=4, dim=dim, bias_var=0.01)
     _, _, rec_ref = oracle.admm_run([[oracle.translate(t)] for t in raws_train],
                                     [oracle.translate(t) for t in raws_test], conf)
-    rec_gpu, final = _run_gpu(ctx, raws_train, raws_test, conf, dim)
+    rec_gpu, final = _run_gpu(ctx, raws_train, raws_test, conf, dim, multi=multi)
     _compare(rec_gpu, rec_ref, rtol=1e-5, atol=1e-7)
     # the FTRL state kept on the last iteration (src/workers.cc:81-85) matches too
     wk, _, _ = oracle.admm_run([[oracle.translate(t)] for t in raws_train],

@@ -171,6 +171,43 @@ def test_ftrl_rows_with_repeated_columns(ctx, oracle):
         close(g, r, atol=1e-6)
 
 
+def test_ftrl_multi_pass_equals_single_passes(ctx):
+    """many workers' row-by-row passes in one launch: each bit-identical to its own launch"""
+    from oracle import oracle as orc
+    dim = 40000
+    raws = [make_synth_csr(900, dim, 30, seed=61),                       # rows up to 64 entries, unit values
+            make_synth_csr(700, dim, 90, seed=62),                       # rows up to 128 entries
+            make_synth_csr(800, dim, 25, seed=63, binary=False),         # stored values
+            make_synth_csr(300, dim, 200, seed=64),                      # rows too long for the pipelined kernel
+            orc.Csr(np.array([0, 3, 5], np.uint64), np.array([2, 2, 5, 1, 1], np.uint32),
+                    np.ones(5, np.float32), np.array([1, 0], np.float32), dim),  # repeated columns
+            make_synth_csr(0, dim, 5, seed=65)]                          # no rows
+    sets = [ctx.csr_upload(r.rowptr, r.col, r.val, r.label, dim) for r in raws]
+    sets[1].relabel_by_frequency()
+    rng = np.random.default_rng(6)
+    off = ctx.vec(dim, rng.normal(0, 0.01, dim).astype(np.float32))
+    reg = ctx.vec(dim, rng.normal(0, 0.01, dim).astype(np.float32))
+    prm = (0.05, 1.0, 0.01, 0.5)
+
+    def fresh():
+        return [[ctx.vec(dim) for _ in sets] for _ in range(3)]
+    w1, z1, n1 = fresh()
+    w2, z2, n2 = fresh()
+    for _ in range(2):                                                   # state carried over, as between parts
+        for k, s in enumerate(sets):
+            s.ftrl_pass(w1[k], z1[k], n1[k], off, reg, *prm)
+        ctx.ftrl_pass_multi(sets, w2, z2, n2, [off] * len(sets), [reg] * len(sets), *prm)
+    for k in range(len(sets)):
+        for a, b in ((w1, w2), (z1, z2), (n1, n2)):
+            np.testing.assert_array_equal(a[k].download(), b[k].download())
+    assert np.abs(z2[0].download()).max() > 0
+    from admm_amd import capi
+    with pytest.raises(capi.AdmmError):
+        ctx.ftrl_pass_multi(sets[:2], [w2[0], w2[0]], z2[:2], n2[:2], [off] * 2, [reg] * 2, *prm)
+    for s in sets:
+        s.destroy()
+
+
 @pytest.mark.parametrize("batch", [64, 500])
 def test_ftrl_minibatch(ctx, oracle, batch):
     dim = 301
