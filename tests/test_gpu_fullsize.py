@@ -110,3 +110,72 @@ def test_ftrl_minibatch_of_one_panel_matches_sums(big):
     assert hz[0] == pytest.approx(float((0.5 - label).sum()), rel=1e-6, abs=1e-3)
     assert hn.sum() == pytest.approx(0.25 * s.nnz, rel=1e-6)             # every stored entry once
     s.destroy()
+
+
+def test_single_pass_ftrl_at_ten_million_rows():
+    """The single-pass FTRL shape (10M rows x 2^20 features, ~40 entries per row): the row-by-row
+    pass of 1024 workers in one launch, and the mini-batch pass of one worker.  Properties: the
+    first step of every worker from zero state is known in closed form, squared-gradient sums are
+    bounded by the entry counts, both modes learn (logloss below ln 2 on fresh rows)."""
+    from admm_amd import capi
+    ctx = capi.Context(0)
+    dim, workers, per = 1 << 20, 1024, 9766
+    shards = [ctx.csr_synth(per, dim, 47, seed=21, row_offset=k * per) for k in range(workers)]
+    assert sum(s.nrows for s in shards) >= 10_000_000
+    w, z, n = ([ctx.vec(dim) for _ in shards] for _ in range(3))
+    off, reg = ctx.vec(dim), ctx.vec(dim)
+    ctx.ftrl_pass_multi(shards, w, z, n, [off] * workers, [reg] * workers, 0.1, 1.0, 1.0, 1.0)
+    test = ctx.csr_synth(200_000, dim, 47, seed=22)
+    for k in (0, 511, 1023):
+        hn = n[k].download().astype(np.float64)
+        # every row adds g^2 <= 1 to the bias column and to each of its stored columns
+        assert 0 < hn[0] <= shards[k].nrows and hn.sum() <= shards[k].nnz
+        assert hn[0] == hn.max()
+        ll, auc, _ = test.metrics([w[k]])
+        assert ll < 0.6931 and auc > 0.6
+    # a second pass over the same shard moves the state on and stays finite
+    n_before = n[5].download()
+    ctx.ftrl_pass_multi(shards[5:6], w[5:6], z[5:6], n[5:6], [off], [reg], 0.1, 1.0, 1.0, 1.0)
+    n_after = n[5].download()
+    assert np.isfinite(n_after).all() and (n_after >= n_before).all() and n_after[0] > n_before[0]
+    for v in w + z + n:
+        v.free()
+    for s in shards:
+        s.destroy()
+    one = ctx.csr_synth(10_000_000, dim, 47, seed=21).build_transposed(panel_rows=65536, col_block=8192)
+    wv, zv, nv = (ctx.vec(dim) for _ in range(3))
+    one.ftrl_pass(wv, zv, nv, off, reg, 0.1, 1.0, 1.0, 1.0, batch=65536)
+    ll, auc, _ = test.metrics([wv])
+    assert ll < 0.6931 and auc > 0.7
+    hn = nv.download().astype(np.float64)
+    assert hn.sum() <= one.nnz and hn[0] <= one.nrows
+    one.destroy()
+    test.destroy()
+    ctx.close()
+
+
+def test_heavy_tailed_rows_over_sixteen_million_features():
+    """Log-normal row lengths (a few rows of many hundreds of entries among short ones) hashed over
+    2^24 features: the sweeps' answers do not depend on how the rows fall into tiles and panels."""
+    from admm_amd import capi
+    ctx = capi.Context(0)
+    dim = 1 << 24
+    kw = dict(seed=31, len_dist=1, tail_sigma=1.2, max_len=1024)
+    a = ctx.csr_synth(400_000, dim, 40, **kw).build_transposed(col_block=16384).relabel_by_frequency()
+    b = ctx.csr_synth(400_000, dim, 40, **kw).build_transposed(panel_rows=50_000, col_block=4096)
+    rp = a.download()[0].astype(np.int64)
+    lens = np.diff(rp)
+    assert lens.max() > 8 * lens.mean()                                  # the tail is there
+    rng = np.random.default_rng(2)
+    x = ctx.vec(dim, (rng.normal(0, 0.05, dim) * (rng.random(dim) < 0.05)).astype(np.float32))
+    ga, gb = ctx.vec(dim), ctx.vec(dim)
+    fa = a.logistic_fg(x, ga, rho=0.0)
+    fb = b.logistic_fg(x, gb, rho=0.0)
+    assert fa == pytest.approx(fb, rel=1e-6)
+    ha, hb = ga.download(), gb.download()
+    np.testing.assert_allclose(ha, hb, rtol=2e-5, atol=2e-5 * np.abs(hb).max())
+    # the bias coordinate of X^T r is the sum of the residuals, whose sum over the loss is checkable
+    assert ha[0] == pytest.approx(hb[0], rel=1e-6)
+    a.destroy()
+    b.destroy()
+    ctx.close()
