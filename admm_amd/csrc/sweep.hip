@@ -427,13 +427,20 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
         constexpr int kRowsPerWave = 64 / kFwLanesPerRow;
         const int r0w = wave * kRowsPerWave;
         const int nrw = nr - r0w < kRowsPerWave ? nr - r0w : kRowsPerWave;
+        // (a row's mask and residual are broadcast with v_readlane: scalar results, no LDS trip;
+        // the scalar mask then is the lane predicate itself)
+        auto bcast = [](unsigned long long v, int src) {
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+          return ((unsigned long long)hi << 32) | lo;
+        };
         for (int r = 0; r < nrw; ++r) {
-          const unsigned long long m = __shfl(my_m, r * kFwLanesPerRow, 64);
-          const unsigned long long rv = __shfl(my_r, r * kFwLanesPerRow, 64);
-          const bool on = (m >> lane) & 1ull;
+          const unsigned long long m = bcast(my_m, r * kFwLanesPerRow);
+          const unsigned long long rv = bcast(my_r, r * kFwLanesPerRow);
+          const bool on = __builtin_amdgcn_inverse_ballot_w64(m);  // lane k <- bit k of the scalar mask
           h1 += on ? rv : 0ull;
           if (MODE == FWD_FTRL) {
-            const unsigned long long rv2 = __shfl(my_r2, r * kFwLanesPerRow, 64);
+            const unsigned long long rv2 = bcast(my_r2, r * kFwLanesPerRow);
             h2 += on ? rv2 : 0ull;
             hseen |= m;
           }
