@@ -50,13 +50,14 @@ __device__ inline float clamp35(float m) { return fmaxf(fminf(m, 35.0f), -35.0f)
 // kFwProducers streaming threads; a tile is up to kFwRowSlots consecutive rows (the launch picks
 // the count so that a tile's stored entries normally fit one chunk of kFwChunk entries); the
 // first kFwHot entries of the gathered vector are cached in LDS.
-constexpr int kFwConsumers = 256;
 constexpr int kFwProducers = 512;
-constexpr int kFwThreads = kFwConsumers + kFwProducers;
+// consumer threads (512, with the leaner producers of a set without values in a 1024-thread
+// workgroup, measured no faster)
+constexpr int fw_consumers(bool) { return 256; }
+constexpr int fw_threads(bool hasval) { return fw_consumers(hasval) + kFwProducers; }
 constexpr int kFwRowSlots = 128;
 constexpr int kFwChunk = 8192;
 constexpr int kFwHot = 16384;
-constexpr int kFwLanesPerRow = kFwConsumers / kFwRowSlots;  // 2
 constexpr int kFwSlots = 4;                                  // tiles whose row data is resident in LDS
 constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 1) * kFwRowSlots) +
                           sizeof(unsigned long long) * (kFwSlots * (kFwRowSlots + 2) + kFwSlots * kFwRowSlots +
@@ -83,8 +84,11 @@ constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kF
 // first use of a load issued under a branch the compiler would wait for ALL outstanding loads
 // after every single gather, and an unconditional gather costs the pipe a clock per lane even
 // for lanes that fetch nothing.
-template <int MODE>
-__global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
+template <int MODE, bool HASVAL>
+__global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
+  constexpr int kFwConsumers = fw_consumers(HASVAL), kFwThreads = fw_threads(HASVAL);
+  constexpr int kFwLanesPerRow = kFwConsumers / kFwRowSlots;  // 2 or 4
+  constexpr uint32_t kBlank = 0xFFFFFFFFu;  // pattern sets: column id of a register slot that holds no entry
   extern __shared__ unsigned long long fw_lds[];
   unsigned long long *rp0 = fw_lds;                                     // [kFwSlots][kFwRowSlots + 2] row pointers
   unsigned long long *mask0 = rp0 + kFwSlots * (kFwRowSlots + 2);       // [kFwSlots][kFwRowSlots] hot masks
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   float *tab = hot + kFwHot;                                            // [8][256] byte -> sum of hot weights
   float *lab0 = tab + 8 * 256;                                          // [kFwSlots][kFwRowSlots] labels
   float *out_s = lab0 + kFwSlots * kFwRowSlots;                         // [kFwRowSlots] per-row results of the tile
-  __shared__ double shred[kFwThreads / 64];
+  __shared__ double shred[16];
   // after the tile loop the product buffer is free: per-wave column sums are combined there
   unsigned long long(*hsum)[64] = reinterpret_cast<unsigned long long(*)[64]>(prod0);
   constexpr int H = kFwChunk / (4 * kFwProducers);  // 16-byte loads per producer thread and chunk
@@ -112,7 +116,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   const float *__restrict__ wsum = a.w[0];
   const uint32_t nhot = a.nhot;
   const bool dense = a.hmask != nullptr;
-  const bool hasval = a.val != nullptr;
+  constexpr bool hasval = HASVAL;
   const bool colsums = dense && MODE != FWD_EVAL;  // X^T r of the mask columns is wanted
   for (uint32_t j = tid; j < nhot; j += kFwThreads) hot[j] = wsum[j];
   if (tid < 2 * 64 * kWarmWords + kWarmWords) wacc[tid] = 0ull;  // wacc, wacc2, wseen are contiguous
@@ -160,7 +164,8 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
   // Gathers of the weights that are not in the LDS copy.  LO / HI are the tile's first and
   // one-past-last entry as positions inside the chunk; register slots outside [LO, HI) (the chunk
   // starts 16-byte aligned, and slots past the tile's end hold a repeat of its last group) are
-  // blanked here once -- column 0, value 0 -- so that no later step needs a range check.
+  // blanked here once -- column 0 and value 0, or a blank column id in a set without values -- so that no later
+  // step needs a range check.
 #define FW_GATHER(LO, HI)                                                                             \
   _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
     const uint32_t p_ = (uint32_t)(h * (4 * kFwProducers) + ptid * 4);                                \
@@ -169,16 +174,16 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       float vv[4] = {xv[h].x, xv[h].y, xv[h].z, xv[h].w};                                             \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
         const bool out = p_ + e < (LO) || p_ + e >= (HI);                                             \
-        cc[e] = out ? 0u : cc[e];                                                                     \
+        cc[e] = out ? (HASVAL ? 0u : kBlank) : cc[e];                                                 \
         vv[e] = out ? 0.0f : vv[e];                                                                   \
       }                                                                                               \
       xc[h] = u32x4{cc[0], cc[1], cc[2], cc[3]};                                                      \
-      xv[h] = f32x4{vv[0], vv[1], vv[2], vv[3]};                                                      \
+      if (HASVAL) xv[h] = f32x4{vv[0], vv[1], vv[2], vv[3]};                                          \
     }                                                                                                 \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
       gw[4 * h + e] = 0.0f;                                                                           \
       const uint32_t off_ = cc[e] << 2;                                                               \
-      if (cc[e] >= nhot)                                                                              \
+      if (cc[e] >= nhot && (HASVAL || cc[e] != kBlank))                                               \
         asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(gw[4 * h + e]) : "v"(off_), "s"(wres) : "memory"); \
     }                                                                                                 \
   }
@@ -203,7 +208,8 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       float pr[4];                                                                                    \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
         const float hv = hot[cc[e] < nhot ? cc[e] : 0u]; /* read, then select: no pointer select */  \
-        pr[e] = (cc[e] < nhot ? hv : gw[4 * h + e]) * vv[e];                                          \
+        const float wj = cc[e] < nhot ? hv : gw[4 * h + e];                                           \
+        pr[e] = HASVAL ? wj * vv[e] : (cc[e] == kBlank ? 0.0f : wj);                                  \
       }                                                                                               \
       *reinterpret_cast<float4 *>((PROD) + p_) = make_float4(pr[0], pr[1], pr[2], pr[3]);             \
     }                                                                                                 \
@@ -276,7 +282,10 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
       // the streamed registers of the next tile are complete from here on (the compiler waits for
       // them in front of this statement, not somewhere among the gathers below)
 #pragma unroll
-      for (int h = 0; h < H; ++h) asm volatile("" : "+v"(xc[h]), "+v"(xv[h])::"memory");
+      for (int h = 0; h < H; ++h) {
+        if (HASVAL) asm volatile("" : "+v"(xc[h]), "+v"(xv[h])::"memory");
+        else asm volatile("" : "+v"(xc[h])::"memory");
+      }
       if (has2) {
         const unsigned long long *rp2 = rp0 + (int)((i + 2) % kFwSlots) * (kFwRowSlots + 2);
         const unsigned long long B2 = rp2[0], E2 = rp2[tile_rows(tile_of(i + 2))];
@@ -323,7 +332,7 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         xc[h] = yc[h];
-        xv[h] = yv[h];
+        if (HASVAL) xv[h] = yv[h];
       }
     } else {
       // ---- consumers --------------------------------------------------------------------------
@@ -368,13 +377,13 @@ __global__ void __launch_bounds__(kFwThreads) k_forward(FwdArgs a) {
           rowsum += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
         }
       }
-      // warm columns: the row's two lanes take the even and the odd bits of its warm words and walk
+      // warm columns: the row's lanes take every second (fourth) bit of its warm words each and walk
       // their set bits, two LDS reads per trip
-      static_assert(kFwLanesPerRow == 2, "even / odd bit split");
+      static_assert(kFwLanesPerRow == 2 || kFwLanesPerRow == 4, "every second or every fourth bit per lane");
       unsigned long long my_w[kWarmWords];
 #pragma unroll
       for (int w = 0; w < kWarmWords; ++w) {
-        const unsigned long long half = q ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+        const unsigned long long half = (kFwLanesPerRow == 2 ? 0x5555555555555555ull : 0x1111111111111111ull) << q;
         my_w[w] = (dense && trow < nr) ? (warm0[((i & 1) * kFwRowSlots + trow) * kWarmWords + w] & half) : 0ull;
         unsigned long long m = my_w[w];
         while (m) {
@@ -584,9 +593,12 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.dim = (uint32_t)csr->dim;
   static bool raised = false;
   if (!raised) {
-    for (const void *fn : {reinterpret_cast<const void *>(&k_forward<FWD_EVAL>),
-                           reinterpret_cast<const void *>(&k_forward<FWD_LBFGS>),
-                           reinterpret_cast<const void *>(&k_forward<FWD_FTRL>)})
+    for (const void *fn : {reinterpret_cast<const void *>(&k_forward<FWD_EVAL, true>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_LBFGS, true>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_FTRL, true>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_EVAL, false>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_LBFGS, false>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_FTRL, false>)})
       ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds));
     raised = true;
   }
@@ -598,15 +610,22 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
     a.rows_per_tile = (uint32_t)std::min<double>(kFwRowSlots, std::max(8.0, std::floor(fit / 8.0) * 8.0));
   }
   const uint64_t ntiles = (r1 - r0 + a.rows_per_tile - 1) / a.rows_per_tile;
-  const int grid = grid_for(ntiles * kFwThreads, kFwThreads, ctx->cu_count);
+  const bool hasval = a.val != nullptr;
+  const int threads = hasval ? fw_threads(true) : fw_threads(false);
+  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)ctx->cu_count));  // one workgroup per CU
   *nblocks_out = grid;
   KernelTimer t(ctx, mode == FWD_EVAL ? ADMM_K_FORWARD_EVAL : ADMM_K_FORWARD);
-  if (mode == FWD_EVAL)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FWD_EVAL>), dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
-  else if (mode == FWD_LBFGS)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FWD_LBFGS>), dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FWD_FTRL>), dim3(grid), dim3(kFwThreads), kFwLds, ctx->stream, a);
+#define FW_LAUNCH(M)                                                                                       \
+  if (hasval) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<M, true>), dim3(grid), dim3(threads), kFwLds, ctx->stream, a); \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<M, false>), dim3(grid), dim3(threads), kFwLds, ctx->stream, a);
+  if (mode == FWD_EVAL) {
+    FW_LAUNCH(FWD_EVAL)
+  } else if (mode == FWD_LBFGS) {
+    FW_LAUNCH(FWD_LBFGS)
+  } else {
+    FW_LAUNCH(FWD_FTRL)
+  }
+#undef FW_LAUNCH
   ADMM_HIP_CHECK(hipGetLastError());
   return ADMM_OK;
 }

@@ -341,8 +341,9 @@ def test_synth_generator_properties(ctx):
     c.build_transposed().relabel_by_frequency()
     fa = a.logistic_fg(x, ga, rho=0.0)
     fc = c.logistic_fg(x, gc, rho=0.0)
-    assert fa == fc
-    np.testing.assert_array_equal(ga.download(), gc.download())
+    # (the two forms reduce a row with a different number of lanes: equal up to float rounding)
+    assert fa == pytest.approx(fc, rel=1e-6)
+    np.testing.assert_allclose(ga.download(), gc.download(), rtol=1e-5, atol=1e-5 * np.abs(gc.download()).max())
     a.destroy()
     b.destroy()
     c.destroy()
