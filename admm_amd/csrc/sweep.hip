@@ -64,31 +64,34 @@ constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kF
                                                         2 * kFwRowSlots * kWarmWords + 2 * 64 * kWarmWords + kWarmWords) + 64;
 
 // CSR-stream forward sweep.  The stored entries of a tile's rows are one contiguous range of
-// col/val.  Producer threads stream it with 16-byte loads (four entries per lane per load),
-// gather the weight of each entry, and park the products in LDS in storage order; consumer
-// threads (two lanes per row) add up each row's slice of LDS, run the sigmoid / loss epilogue
-// once per row, and accumulate X^T r of the mask columns.
+// col/val.  Producer threads stream it (one entry per lane per load, so that a wave-wide load
+// covers 64 consecutive entries), fetch the weight of each entry, and leave the products in LDS in
+// storage order; consumer threads (two lanes per row) add up each row's slice of LDS, run the
+// sigmoid / loss epilogue once per row, and accumulate X^T r of the mask columns.
 //
-// The gather is what bounds this kernel: a wave-wide gather of scattered floats costs the vector
-// memory pipe 2 clocks per active lane when it hits L2 (6.6 when it does not), and only when
-// enough of them are in flight.  The sample set's columns are therefore relabelled by decreasing
+// The gather is what bounds this kernel: a wave-wide gather of scattered floats costs the memory
+// system about 2 clocks per active lane when it hits L2 (every lane pulls a whole line into L1),
+// more when it does not.  The sample set's columns are therefore relabelled by decreasing
 // frequency (power-law data: a few thousand columns hold most entries), the gathered vector
 // `wsum` is stored in that order, and its first kFwHot entries are kept in LDS, where a gather is
 // an order of magnitude cheaper.
 //
 // A wave that issues loads stalls until the memory pipe has accepted them, so the waves that
 // feed the pipe do nothing else: while the consumers reduce tile i (product buffer half i & 1),
-// the producers issue the stream of tile i+2 and, behind it, the gathers of tile i+1, wait, and
-// write the products of tile i+1 to the other half.  Both roles meet at the same barriers.
-// The gathers are exec-masked loads written as inline assembly with one explicit wait: at the
-// first use of a load issued under a branch the compiler would wait for ALL outstanding loads
-// after every single gather, and an unconditional gather costs the pipe a clock per lane even
-// for lanes that fetch nothing.
+// the producers issue the stream of tile i+2, make the products of tile i+1 in the other half,
+// wait, and meet the consumers at the barrier that ends the step.
+// The weights outside the LDS copy are fetched by exec-masked `buffer_load_dword ... lds`
+// instructions, which the memory pipe completes by writing LDS itself: lanes whose column is in
+// the LDS copy (or past the tile's end) are masked off and cost the pipe nothing, and no register
+// is written behind the compiler's back (a gather into registers under a branch makes the
+// compiler wait for ALL outstanding loads at its first use, and hiding the load from the compiler
+// in inline assembly is only correct while the compiler happens not to copy the destination
+// register before the data lands).  Sets with values multiply the gathered weights in place
+// after the wait.
 template <int MODE, bool HASVAL>
 __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   constexpr int kFwConsumers = fw_consumers(HASVAL), kFwThreads = fw_threads(HASVAL);
   constexpr int kFwLanesPerRow = kFwConsumers / kFwRowSlots;  // 2 or 4
-  constexpr uint32_t kBlank = 0xFFFFFFFFu;  // pattern sets: column id of a register slot that holds no entry
   extern __shared__ unsigned long long fw_lds[];
   unsigned long long *rp0 = fw_lds;                                     // [kFwSlots][kFwRowSlots + 2] row pointers
   unsigned long long *mask0 = rp0 + kFwSlots * (kFwRowSlots + 2);       // [kFwSlots][kFwRowSlots] hot masks
@@ -104,7 +107,6 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   __shared__ double shred[16];
   // after the tile loop the product buffer is free: per-wave column sums are combined there
   unsigned long long(*hsum)[64] = reinterpret_cast<unsigned long long(*)[64]>(prod0);
-  constexpr int H = kFwChunk / (4 * kFwProducers);  // 16-byte loads per producer thread and chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const bool producer = tid >= kFwConsumers;
@@ -136,88 +138,76 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   // per-lane sums of the 64 mask columns over the rows this wave has seen (lane k <-> column k)
   unsigned long long h1 = 0, h2 = 0, hseen = 0;
 
-  // producers: two register sets of streamed entries, X = the tile whose gathers are next,
-  // Y = the one after it; gw = gathered weights
-  u32x4 xc[H], yc[H];
-  f32x4 xv[H], yv[H];
-  float gw[4 * H];
+  // Producers keep two register sets of streamed entries, one dword per lane and load: entry
+  // j * kFwProducers + ptid of the tile's chunk, so that the 64 entries of one wave-wide load are
+  // consecutive in the product buffer.  X = the tile whose products are made next, Y = the one
+  // after it.
+  constexpr int J = kFwChunk / kFwProducers;  // loads per producer thread and chunk
+  uint32_t xc[J], yc[J];
+  float xv[J], yv[J];  // sets with values only
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    xc[h] = yc[h] = u32x4{0, 0, 0, 0};
-    xv[h] = yv[h] = f32x4{0, 0, 0, 0};
+  for (int j = 0; j < J; ++j) {
+    xc[j] = yc[j] = 0u;
+    xv[j] = yv[j] = 0.0f;
   }
+  const int pwave = __builtin_amdgcn_readfirstlane(ptid >> 6);
   // the gathered vector as a buffer resource (dim * 4 bytes)
   const uint64_t wbase = reinterpret_cast<uint64_t>(wsum);
   const u32x4 wres = {(uint32_t)wbase, (uint32_t)(wbase >> 32) & 0xFFFFu, a.dim * 4u, 0x00020000u};
-  // 16-byte groups past the tile's end re-read its last group
-#define FW_ISSUE(PC, PV, CB, EE)                                                                      \
-  {                                                                                                   \
-    const unsigned long long last_ = ((EE) > (CB) ? (EE) - 1 : (CB)) & ~3ull;                         \
-    _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                   \
-      unsigned long long k_ = (CB) + (unsigned long long)h * (4 * kFwProducers) + (unsigned long long)ptid * 4; \
-      k_ = k_ < last_ ? k_ : last_;                                                                   \
-      PC[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.col + k_));                \
-      if (hasval) PV[h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.val + k_));    \
-      else PV[h] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};                                                     \
-    }                                                                                                 \
-  }
-  // Gathers of the weights that are not in the LDS copy.  LO / HI are the tile's first and
-  // one-past-last entry as positions inside the chunk; register slots outside [LO, HI) (the chunk
-  // starts 16-byte aligned, and slots past the tile's end hold a repeat of its last group) are
-  // blanked here once -- column 0 and value 0, or a blank column id in a set without values -- so that no later
-  // step needs a range check.
-#define FW_GATHER(LO, HI)                                                                             \
-  _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
-    const uint32_t p_ = (uint32_t)(h * (4 * kFwProducers) + ptid * 4);                                \
-    uint32_t cc[4] = {xc[h].x, xc[h].y, xc[h].z, xc[h].w};                                            \
-    if (p_ < (LO) || p_ + 4 > (HI)) {                                                                 \
-      float vv[4] = {xv[h].x, xv[h].y, xv[h].z, xv[h].w};                                             \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
-        const bool out = p_ + e < (LO) || p_ + e >= (HI);                                             \
-        cc[e] = out ? (HASVAL ? 0u : kBlank) : cc[e];                                                 \
-        vv[e] = out ? 0.0f : vv[e];                                                                   \
-      }                                                                                               \
-      xc[h] = u32x4{cc[0], cc[1], cc[2], cc[3]};                                                      \
-      if (HASVAL) xv[h] = f32x4{vv[0], vv[1], vv[2], vv[3]};                                          \
-    }                                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-      gw[4 * h + e] = 0.0f;                                                                           \
-      const uint32_t off_ = cc[e] << 2;                                                               \
-      if (cc[e] >= nhot && (HASVAL || cc[e] != kBlank))                                               \
-        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(gw[4 * h + e]) : "v"(off_), "s"(wres) : "memory"); \
-    }                                                                                                 \
-  }
-  // The wait names every gathered register as read and written, so no instruction that uses one of
-  // them can be scheduled in front of it.
-#define FW_WAIT_GATHERS()                                                                             \
-  {                                                                                                   \
-    static_assert(H == 4, "operand list below is written for 16 gathered registers");                 \
-    asm volatile("s_waitcnt vmcnt(0)"                                                                 \
-                 : "+v"(gw[0]), "+v"(gw[1]), "+v"(gw[2]), "+v"(gw[3]), "+v"(gw[4]), "+v"(gw[5]), "+v"(gw[6]),    \
-                   "+v"(gw[7]), "+v"(gw[8]), "+v"(gw[9]), "+v"(gw[10]), "+v"(gw[11]), "+v"(gw[12]), "+v"(gw[13]), \
-                   "+v"(gw[14]), "+v"(gw[15])                                                         \
-                 :                                                                                    \
-                 : "memory");                                                                         \
-  }
-#define FW_PRODUCTS(PROD, HI)                                                                         \
-  _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                     \
-    const uint32_t p_ = (uint32_t)(h * (4 * kFwProducers) + ptid * 4);                                \
-    if (p_ < (HI)) {                                                                                  \
-      const uint32_t cc[4] = {xc[h].x, xc[h].y, xc[h].z, xc[h].w};                                    \
-      const float vv[4] = {xv[h].x, xv[h].y, xv[h].z, xv[h].w};                                       \
-      float pr[4];                                                                                    \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
-        const float hv = hot[cc[e] < nhot ? cc[e] : 0u]; /* read, then select: no pointer select */  \
-        const float wj = cc[e] < nhot ? hv : gw[4 * h + e];                                           \
-        pr[e] = HASVAL ? wj * vv[e] : (cc[e] == kBlank ? 0.0f : wj);                                  \
-      }                                                                                               \
-      *reinterpret_cast<float4 *>((PROD) + p_) = make_float4(pr[0], pr[1], pr[2], pr[3]);             \
-    }                                                                                                 \
-  }
-  // a tile's [LO, HI) from its first and one-past-last stored entry
-#define FW_RANGE(BB, EE, LO, HI)                                                                      \
-  const uint32_t LO = (uint32_t)((BB) & 3ull);                                                        \
-  const uint32_t HI = (uint32_t)(((EE) - ((BB) & ~3ull)) < (unsigned long long)kFwChunk ? ((EE) - ((BB) & ~3ull)) : (unsigned long long)kFwChunk);
+  // Stream of one tile: its stored entries [B, E) (at most one chunk of them) through a buffer
+  // resource that starts at the tile's first entry; lanes past the tile's end read zero.
+  auto issue_stream = [&](uint32_t (&pc)[J], float (&pv)[J], unsigned long long B, unsigned long long E) {
+    const unsigned long long n = E - B < (unsigned long long)kFwChunk ? E - B : (unsigned long long)kFwChunk;
+    const __amdgpu_buffer_rsrc_t rc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.col + B), 0, (int)(n * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < J; ++j) pc[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, ptid * 4, j * kFwProducers * 4, 2);
+    if (HASVAL) {
+      const __amdgpu_buffer_rsrc_t rv =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.val + B), 0, (int)(n * 4), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        pv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, ptid * 4, j * kFwProducers * 4, 2));
+    }
+  };
+  // Gathers of the weights that are not in the LDS copy: exec-masked buffer loads that the memory
+  // pipe writes straight into the product buffer (lane l of a wave-wide load lands at the
+  // destination base + 4 l, which is this wave's stretch of the chunk; inactive lanes leave their
+  // words alone).  No register is written behind the compiler's back; the wait below retires them.
+  auto gather_tail = [&](const uint32_t (&pc)[J], float *pbuf, uint32_t n) {
+    const uint32_t dst0 = (uint32_t)(uintptr_t)pbuf + (uint32_t)pwave * 256u;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const uint32_t p = (uint32_t)(j * kFwProducers + ptid);
+      const uint32_t off = pc[j] << 2;
+      const uint32_t dst = dst0 + (uint32_t)j * (kFwProducers * 4u);
+      if (p < n && pc[j] >= nhot) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(off), "s"(dst), "s"(wres)
+                     : "memory");
+      }
+    }
+  };
+  auto hot_products = [&](const uint32_t (&pc)[J], const float (&pv)[J], float *pbuf, uint32_t n) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const uint32_t p = (uint32_t)(j * kFwProducers + ptid);
+      if (p < n && pc[j] < nhot) pbuf[p] = HASVAL ? hot[pc[j]] * pv[j] : hot[pc[j]];
+    }
+  };
+  // sets with values: the gathered weights are multiplied in place once they have landed
+  auto scale_tail = [&](const uint32_t (&pc)[J], const float (&pv)[J], float *pbuf, uint32_t n) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const uint32_t p = (uint32_t)(j * kFwProducers + ptid);
+      if (p < n && pc[j] >= nhot) pbuf[p] *= pv[j];
+    }
+  };
+  auto chunk_len = [&](unsigned long long B, unsigned long long E) {
+    return (uint32_t)(E - B < (unsigned long long)kFwChunk ? E - B : (unsigned long long)kFwChunk);
+  };
 
   // this workgroup's tiles: blockIdx.x + i * gridDim.x
   const uint64_t nmine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
@@ -245,96 +235,116 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   if (producer) {
     if (nmine > 0) {
       const unsigned long long B = rp0[0], E = rp0[tile_rows(tile_of(0))];
-      FW_RANGE(B, E, lo0, hi0)
-      FW_ISSUE(xc, xv, B & ~3ull, E)
-      FW_GATHER(lo0, hi0)
-      FW_WAIT_GATHERS()
-      FW_PRODUCTS(prod0, hi0)
+      const uint32_t n0 = chunk_len(B, E);
+      issue_stream(yc, yv, B, E);
+      gather_tail(yc, prod0, n0);
+      hot_products(yc, yv, prod0, n0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (HASVAL) scale_tail(yc, yv, prod0, n0);
     }
     if (nmine > 1) {
       const unsigned long long *rp = rp0 + 1 * (kFwRowSlots + 2);
-      const unsigned long long B = rp[0], E = rp[tile_rows(tile_of(1))];
-      FW_ISSUE(xc, xv, B & ~3ull, E)
+      issue_stream(xc, xv, rp[0], rp[tile_rows(tile_of(1))]);
     }
   }
   __syncthreads();
-  for (uint64_t i = 0; i < nmine; ++i) {
-    const int slot = (int)(i % kFwSlots), slot1 = (int)((i + 1) % kFwSlots), slot3 = (int)((i + 3) % kFwSlots);
-    const unsigned long long *rp = rp0 + slot * (kFwRowSlots + 2);
-    const unsigned long long *mask_s = mask0 + slot * kFwRowSlots;
-    float *prod = prod0 + (i & 1) * kFwChunk;
-    const uint64_t tile = tile_of(i);
-    const int nr = tile_rows(tile);
-    const unsigned long long B = rp[0], E = rp[nr];
-    const unsigned long long cb0 = B & ~3ull;
-    // tiles whose rows are so long that they do not fit one chunk take extra passes, each
-    // bracketed by two barriers that both roles execute
+  // The two roles run separate tile loops (same trip count, one barrier per tile each), so the
+  // registers a producer keeps across tiles are not live in the consumers' code and vice versa.
+  // The role is wave-uniform; readfirstlane lets the compiler branch on a scalar.
+#define FW_TILE_HEAD \
+    const int slot = (int)(i % kFwSlots), slot1 = (int)((i + 1) % kFwSlots), slot3 = (int)((i + 3) % kFwSlots); \
+    const unsigned long long *rp = rp0 + slot * (kFwRowSlots + 2); \
+    const unsigned long long *mask_s = mask0 + slot * kFwRowSlots; \
+    float *prod = prod0 + (i & 1) * kFwChunk; \
+    const uint64_t tile = tile_of(i); \
+    const int nr = tile_rows(tile); \
+    const unsigned long long B = rp[0], E = rp[nr]; \
+    const unsigned long long cb0 = B; \
     const bool has1 = i + 1 < nmine, has2 = i + 2 < nmine, has3 = i + 3 < nmine;
-    if (producer) {
-      // ---- producers --------------------------------------------------------------------------
-      uint32_t hi1 = 0;
-      // per-row results of the previous tile (the consumers left them in LDS: a store from a
-      // consumer wave would queue behind everything the producers have in the memory pipe)
-      if (i > 0) {
-        const uint64_t ptile = tile_of(i - 1);
-        if (ptid < tile_rows(ptile)) a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
+  // One producer step: while the consumers reduce tile i, make the products of tile i+1 (held in
+  // the X registers) and stream tile i+2 into the Y registers.
+  const bool gather_first = pwave < kFwProducers / 128;
+  auto produce = [&](uint64_t i, uint32_t (&pxc)[J], float (&pxv)[J], uint32_t (&pyc)[J], float (&pyv)[J]) {
+    FW_TILE_HEAD
+    (void)mask_s;
+    (void)prod;
+    // per-row results of the previous tile (the consumers left them in LDS: a store from a
+    // consumer wave would queue behind everything the producers have in the memory pipe)
+    if (i > 0) {
+      const uint64_t ptile = tile_of(i - 1);
+      if (ptid < tile_rows(ptile)) a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
+    }
+    // row data of the tile three ahead, parked in LDS at the end of the step: producer threads
+    // 0..128 fetch row pointers and labels, the next 128 the masks
+    unsigned long long pf = 0;
+    float pf_lab = 0.0f;
+    int nr3 = 0;
+    if (has3) {
+      const uint64_t rb3 = a.r0 + tile_of(i + 3) * rpt;
+      nr3 = tile_rows(tile_of(i + 3));
+      if (ptid <= nr3) pf = a.rowptr[rb3 + ptid];
+      else if (dense && ptid > kFwRowSlots && ptid - (kFwRowSlots + 1) < nr3) pf = a.hmask[rb3 + ptid - (kFwRowSlots + 1)];
+      if (ptid < nr3) pf_lab = a.label[rb3 + ptid];
+    }
+    // warm mask words of the next tile (needed by the consumers one step from now)
+    unsigned long long pf_warm = 0;
+    const int nw1 = (dense && has1) ? tile_rows(tile_of(i + 1)) * kWarmWords : 0;
+    if (ptid < nw1) pf_warm = a.hwarm[(a.r0 + tile_of(i + 1) * rpt) * kWarmWords + ptid];
+    // the stream of tile i+2 goes out first: it has the whole step to arrive
+    if (has2) {
+      const unsigned long long *rp2 = rp0 + (int)((i + 2) % kFwSlots) * (kFwRowSlots + 2);
+      issue_stream(pyc, pyv, rp2[0], rp2[tile_rows(tile_of(i + 2))]);
+    }
+    float *prodn = prod0 + ((i + 1) & 1) * kFwChunk;
+    uint32_t n1 = 0;
+    if (has1) {
+      const unsigned long long *rp1 = rp0 + slot1 * (kFwRowSlots + 2);
+      n1 = chunk_len(rp1[0], rp1[tile_rows(tile_of(i + 1))]);
+      // Half of the producer waves (one of the two on each SIMD) issue their gathers first and
+      // write the products of the cached columns afterwards, the other half the other way round:
+      // the memory pipe takes gathers from one half while the other half works in LDS.
+      if (gather_first) {
+        gather_tail(pxc, prodn, n1);
+        hot_products(pxc, pxv, prodn, n1);
+      } else {
+        hot_products(pxc, pxv, prodn, n1);
+        gather_tail(pxc, prodn, n1);
       }
-      // the streamed registers of the next tile are complete from here on (the compiler waits for
-      // them in front of this statement, not somewhere among the gathers below)
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        if (HASVAL) asm volatile("" : "+v"(xc[h]), "+v"(xv[h])::"memory");
-        else asm volatile("" : "+v"(xc[h])::"memory");
-      }
-      if (has2) {
-        const unsigned long long *rp2 = rp0 + (int)((i + 2) % kFwSlots) * (kFwRowSlots + 2);
-        const unsigned long long B2 = rp2[0], E2 = rp2[tile_rows(tile_of(i + 2))];
-        FW_ISSUE(yc, yv, B2 & ~3ull, E2)
-      }
-      // row data of the tile three ahead, parked in LDS after the wait below: producer threads
-      // 0..128 fetch row pointers and labels, the next 128 the masks
-      unsigned long long pf = 0;
-      float pf_lab = 0.0f;
-      int nr3 = 0;
-      if (has3) {
-        const uint64_t rb3 = a.r0 + tile_of(i + 3) * rpt;
-        nr3 = tile_rows(tile_of(i + 3));
-        if (ptid <= nr3) pf = a.rowptr[rb3 + ptid];
-        else if (dense && ptid > kFwRowSlots && ptid - (kFwRowSlots + 1) < nr3) pf = a.hmask[rb3 + ptid - (kFwRowSlots + 1)];
-        if (ptid < nr3) pf_lab = a.label[rb3 + ptid];
-      }
-      // warm mask words of the next tile (needed by the consumers one iteration from now)
-      unsigned long long pf_warm = 0;
-      const int nw1 = (dense && has1) ? tile_rows(tile_of(i + 1)) * kWarmWords : 0;
-      if (ptid < nw1) pf_warm = a.hwarm[(a.r0 + tile_of(i + 1) * rpt) * kWarmWords + ptid];
-      if (has1) {
-        const unsigned long long *rp1 = rp0 + slot1 * (kFwRowSlots + 2);
-        const unsigned long long B1 = rp1[0], E1 = rp1[tile_rows(tile_of(i + 1))];
-        FW_RANGE(B1, E1, lo1_, hi1_)
-        hi1 = hi1_;
-        FW_GATHER(lo1_, hi1_)
-      }
-      for (unsigned long long cb = cb0 + kFwChunk; cb < E; cb += kFwChunk) {
-        __syncthreads();
-        __syncthreads();
-      }
-      FW_WAIT_GATHERS()
-      if (has1) {
-        float *prodn = prod0 + ((i + 1) & 1) * kFwChunk;
-        FW_PRODUCTS(prodn, hi1)
-      }
-      if (has3) {
-        if (ptid <= nr3) rp0[slot3 * (kFwRowSlots + 2) + ptid] = pf;
-        else if (ptid > kFwRowSlots && ptid <= 2 * kFwRowSlots) mask0[slot3 * kFwRowSlots + ptid - (kFwRowSlots + 1)] = pf;
-        if (ptid < kFwRowSlots) lab0[slot3 * kFwRowSlots + ptid] = pf_lab;
-      }
-      if (ptid < nw1) warm0[((i + 1) & 1) * kFwRowSlots * kWarmWords + ptid] = pf_warm;
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        xc[h] = yc[h];
-        if (HASVAL) xv[h] = yv[h];
-      }
-    } else {
+    }
+    // tiles whose rows are so long that they do not fit one chunk take extra passes by the
+    // consumers, each bracketed by two barriers that both roles execute
+    for (unsigned long long cb = cb0 + kFwChunk; cb < E; cb += kFwChunk) {
+      __syncthreads();
+      __syncthreads();
+    }
+    // the gathers have landed in LDS after this wait (it also retires the stream issued above,
+    // which has had the whole step)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (HASVAL && has1) scale_tail(pxc, pxv, prodn, n1);
+    if (has3) {
+      if (ptid <= nr3) rp0[slot3 * (kFwRowSlots + 2) + ptid] = pf;
+      else if (ptid > kFwRowSlots && ptid <= 2 * kFwRowSlots) mask0[slot3 * kFwRowSlots + ptid - (kFwRowSlots + 1)] = pf;
+      if (ptid < kFwRowSlots) lab0[slot3 * kFwRowSlots + ptid] = pf_lab;
+    }
+    if (ptid < nw1) warm0[((i + 1) & 1) * kFwRowSlots * kWarmWords + ptid] = pf_warm;
+    __syncthreads();
+  };
+  if (__builtin_amdgcn_readfirstlane(tid) >= kFwConsumers) {
+    // two steps per trip with the register sets swapped: no copies of registers that loads in
+    // flight are still writing
+    for (uint64_t i = 0; i < nmine; i += 2) {
+      produce(i, xc, xv, yc, yv);
+      if (i + 1 < nmine) produce(i + 1, yc, yv, xc, xv);
+    }
+  } else {
+  for (uint64_t i = 0; i < nmine; ++i) {
+    FW_TILE_HEAD
+    (void)slot1;
+    (void)slot3;
+    (void)has1;
+    (void)has2;
+    (void)has3;
+    {
       // ---- consumers --------------------------------------------------------------------------
       float rowsum = 0.0f;
       {
@@ -470,15 +480,12 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
     }
     __syncthreads();
   }
+  }
+#undef FW_TILE_HEAD
   if (producer && nmine > 0) {
     const uint64_t ptile = tile_of(nmine - 1);
     if (ptid < tile_rows(ptile)) a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
   }
-#undef FW_ISSUE
-#undef FW_GATHER
-#undef FW_PRODUCTS
-#undef FW_WAIT_GATHERS
-#undef FW_RANGE
   if (colsums) {
     __syncthreads();
     if (tid < 64 * kWarmWords) {

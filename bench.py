@@ -192,7 +192,7 @@ def main():
             wl = pmc.get("workload", {})
             if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus"), bool(wl.get("explicit_values"))) == \
                     (rows_total, args.dim, world, args.explicit_values):
-                sym = "k_transposed<false" if dom == "transposed_block_sweep" else "k_forward<1>"
+                sym = "k_transposed<false" if dom == "transposed_block_sweep" else "k_forward<1"
                 for name, rec in pmc["kernels"].items():
                     if sym in name:
                         traffic, traffic_src = rec["traffic_bytes"], "profiles/pmc_traffic_c3.json"

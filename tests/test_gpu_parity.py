@@ -366,6 +366,44 @@ def test_sweeps_on_generated_set(ctx, oracle):
     dev.destroy()
 
 
+@pytest.mark.parametrize("explicit_values", [False, True])
+@pytest.mark.parametrize("relabel", [False, True])
+def test_sweeps_many_tiles_per_workgroup(ctx, oracle, relabel, explicit_values):
+    """enough rows that every workgroup of the forward sweep walks a dozen tiles (its software
+    pipeline runs in steady state), in all three forms of the sweep, against the oracle"""
+    from oracle import oracle as orc
+    dim = 1 << 18
+    nrows = 400_000
+    dev = ctx.csr_synth(nrows, dim, 60, seed=12, explicit_values=explicit_values)
+    dev.build_transposed(panel_rows=100_000, col_block=8192)
+    if relabel:
+        dev.relabel_by_frequency()
+    tr = orc.Csr(*dev.download(), dim)
+    rng = np.random.default_rng(8)
+    x = rng.normal(0, 0.1, dim).astype(np.float32)
+    b = rng.normal(0, 0.02, dim).astype(np.float32)
+    z = rng.normal(0, 0.1, dim).astype(np.float32)
+    # objective / gradient
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, b, z, None, 0.05)
+    g = ctx.vec(dim)
+    f = dev.logistic_fg(ctx.vec(dim, x), g, offset=ctx.vec(dim, b), z=ctx.vec(dim, z), rho=0.05)
+    close(f, f_ref)
+    close(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
+    # predictions and metrics
+    s64, p_ref = oracle.logloss_sum_f64(tr, [x, b], want_p=True)
+    close(dev.predict([ctx.vec(dim, x), ctx.vec(dim, b)]), p_ref, atol=1e-6)
+    ll, auc, _ = dev.metrics([ctx.vec(dim, x), ctx.vec(dim, b)])
+    close(ll, s64 / tr.nrows)
+    # mini-batch FTRL
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    oracle.ftrl_run(tr, hw, hz, hn, b, z, 0.05, 1.0, 0.1, 1.0, batch=100_000)
+    w, zz, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    dev.ftrl_pass(w, zz, n, ctx.vec(dim, b), ctx.vec(dim, z), 0.05, 1.0, 0.1, 1.0, batch=100_000)
+    for got, ref in ((w, hw), (zz, hz), (n, hn)):
+        close(got.download(), ref, rtol=5e-5, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    dev.destroy()
+
+
 # ------------------------------------------------------------------------------------------------
 # frequency relabelling is invisible at the boundary
 # ------------------------------------------------------------------------------------------------

@@ -3,8 +3,10 @@ WRITE_SIZE, one pass each) over `bench.py --steps 1 --warmup 0 --no-cpu-baseline
 
     python tools/pmc_traffic.py FETCH.csv WRITE.csv BENCH_LINE.json OUT.json [--tcol-factor F]
 
-Counter values are KB per dispatch.  On gfx950 FETCH_SIZE tallies a 16-byte-per-lane streaming
-read at half its bytes, so the bytes a kernel streams that way are added once more; the factor for
+Counter values are KB per dispatch.  On gfx950 FETCH_SIZE tallies a coalesced streaming read that
+asks for whole 128-byte lines (16 bytes per lane, or a wave-wide run of consecutive dwords: the
+forward sweep's raw count did not move when its stream went from the first form to the second) at
+half its bytes, so the bytes a kernel streams that way are added once more; the factor for
 the 8-byte-per-lane stream of the column-block copy's column field is measured separately (a run of
 the transposed sweep with its gathers switched off, whose bytes are known) and passed in.
 """
@@ -51,7 +53,7 @@ def main():
         "kernels": {},
     }
     for name, (fbytes, n) in fetch.items():
-        if "k_forward<1>" in name:
+        if "k_forward<1" in name:
             s16 = copied * (8 if explicit else 4)            # col (+ val) of the compact row-major form
             s8, alg = 0.0, kern["forward_csr_sweep"]["algorithmic_bytes"]
         elif "k_transposed<false" in name:
