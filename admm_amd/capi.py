@@ -41,11 +41,12 @@ class SynthSpec(C.Structure):
 
 class LbfgsParams(C.Structure):
     _fields_ = [("m", C.c_int), ("max_iter", C.c_int), ("max_linesearch", C.c_int),
-                ("epsilon", C.c_float), ("ftol", C.c_float), ("wolfe", C.c_float)]
+                ("epsilon", C.c_float), ("ftol", C.c_float), ("wolfe", C.c_float), ("linesearch", C.c_int)]
 
 
 class LbfgsResult(C.Structure):
-    _fields_ = [("f", C.c_double), ("evals", C.c_int), ("iters", C.c_int)]
+    _fields_ = [("f", C.c_double), ("evals", C.c_int), ("iters", C.c_int),
+                ("forward_sweeps", C.c_int), ("transposed_sweeps", C.c_int)]
 
 
 _lib = None
@@ -323,9 +324,10 @@ class SampleSet:
     def lbfgs_solve(self, x, offset=None, z=None, ydual=None, rho=0.0, **params):
         p = LbfgsParams(params.get("m", 6), params.get("max_iter", 10),
                         params.get("max_linesearch", 20), params.get("epsilon", 1e-5),
-                        params.get("ftol", 1e-4), params.get("wolfe", 0.9))
+                        params.get("ftol", 1e-4), params.get("wolfe", 0.9), int(params.get("linesearch", 0)))
         res = LbfgsResult()
         _check(self.ctx.L.admm_lbfgs_solve(self.h, x.ptr, offset.ptr if offset else None,
                                            z.ptr if z else None, ydual.ptr if ydual else None,
                                            rho, C.byref(p), C.byref(res)))
-        return dict(f=res.f, evals=res.evals, iters=res.iters)
+        return dict(f=res.f, evals=res.evals, iters=res.iters, forward_sweeps=res.forward_sweeps,
+                    transposed_sweeps=res.transposed_sweeps)

@@ -405,7 +405,7 @@ static void free_csr(admm_csr *c) {
     hipSetDevice(c->ctx->device);
     hipStreamSynchronize(c->ctx->stream);
   }
-  void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_tptr,
+  void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_margin, c->d_dmargin, c->d_tptr,
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol};
   for (void *p : ptrs)

@@ -93,6 +93,8 @@ struct admm_csr {
   float *d_val = nullptr;  // nullptr = implicit 1
   float *d_label = nullptr;
   float *d_rowbuf = nullptr;  // nrows floats: p / residual / per-row gradient scale
+  float *d_margin = nullptr;  // nrows floats each: margins X(x+offset) at the L-BFGS iterate, and X d
+  float *d_dmargin = nullptr;
   float *d_wsum = nullptr;    // dim floats: the vector the forward sweep gathers (relabelled order)
   // columns relabelled by decreasing frequency: d_col holds NEW ids; perm: new -> old, inv: old -> new
   uint32_t *d_perm = nullptr, *d_inv = nullptr;
@@ -151,15 +153,17 @@ int ensure_rowbuf(admm_csr *csr);
 int ensure_taccum(admm_csr *csr);
 
 // sweeps (sweep.hip)
-enum FwdMode { FWD_EVAL = 0, FWD_LBFGS = 1, FWD_FTRL = 2 };
+enum FwdMode { FWD_EVAL = 0, FWD_LBFGS = 1, FWD_FTRL = 2, FWD_MARGIN = 3 };
 struct FwdResult {
   double s0, s1, s2;
 };
 // margins over rows [r0, r1) with up to 4 summed weight vectors; writes csr->d_rowbuf[r]
 // (or out_rows when given) and returns mode-dependent sums through ctx->h_scalars[0..2]
 // (after finish_partials; the caller decides when to read them).
+// FWD_MARGIN writes the plain row sums X w and nothing else; FWD_LBFGS also writes them to
+// margins_out when that is given.
 int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w,
-                   int nw, float *out_rows, int *nblocks_out);
+                   int nw, float *out_rows, int *nblocks_out, float *margins_out = nullptr);
 // transposed sweep over panels [p0, p1): accumulates into csr->d_g1 (and d_g2 / d_mask in FTRL
 // mode), which must be zero on entry
 int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1);

@@ -25,6 +25,7 @@ struct FwdArgs {
   const float *w[4];
   int nw;
   float *out;
+  float *out2;  // FWD_LBFGS: the row sums themselves (nullptr: not wanted)
   double *partials;
   int mode;
   uint32_t rows_per_tile;  // <= kFwRowSlots
@@ -59,7 +60,7 @@ constexpr int kFwRowSlots = 128;
 constexpr int kFwChunk = 8192;
 constexpr int kFwHot = 16384;
 constexpr int kFwSlots = 4;                                  // tiles whose row data is resident in LDS
-constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 1) * kFwRowSlots) +
+constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 2) * kFwRowSlots) +
                           sizeof(unsigned long long) * (kFwSlots * (kFwRowSlots + 2) + kFwSlots * kFwRowSlots +
                                                         2 * kFwRowSlots * kWarmWords + 2 * 64 * kWarmWords + kWarmWords) + 64;
 
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   float *tab = hot + kFwHot;                                            // [8][256] byte -> sum of hot weights
   float *lab0 = tab + 8 * 256;                                          // [kFwSlots][kFwRowSlots] labels
   float *out_s = lab0 + kFwSlots * kFwRowSlots;                         // [kFwRowSlots] per-row results of the tile
+  float *out2_s = out_s + kFwRowSlots;                                  // [kFwRowSlots] row sums of the tile (FWD_LBFGS)
   __shared__ double shred[16];
   // after the tile loop the product buffer is free: per-wave column sums are combined there
   unsigned long long(*hsum)[64] = reinterpret_cast<unsigned long long(*)[64]>(prod0);
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   const uint32_t nhot = a.nhot;
   const bool dense = a.hmask != nullptr;
   constexpr bool hasval = HASVAL;
-  const bool colsums = dense && MODE != FWD_EVAL;  // X^T r of the mask columns is wanted
+  const bool colsums = dense && MODE != FWD_EVAL && MODE != FWD_MARGIN;  // X^T r of the mask columns is wanted
   for (uint32_t j = tid; j < nhot; j += kFwThreads) hot[j] = wsum[j];
   if (tid < 2 * 64 * kWarmWords + kWarmWords) wacc[tid] = 0ull;  // wacc, wacc2, wseen are contiguous
   if (dense) {
@@ -272,7 +274,10 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
     // consumer wave would queue behind everything the producers have in the memory pipe)
     if (i > 0) {
       const uint64_t ptile = tile_of(i - 1);
-      if (ptid < tile_rows(ptile)) a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
+      if (ptid < tile_rows(ptile)) {
+        a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
+        if (MODE == FWD_LBFGS && a.out2) a.out2[a.r0 + ptile * rpt + ptid] = out2_s[ptid];
+      }
     }
     // row data of the tile three ahead, parked in LDS at the end of the step: producer threads
     // 0..128 fetch row pointers and labels, the next 128 the masks
@@ -415,7 +420,9 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
       if (q == 0 && trow < nr) {
         const float m = rowsum;
         const float lab = lab0[slot * kFwRowSlots + trow];
-        if (MODE == FWD_EVAL) {
+        if (MODE == FWD_MARGIN) {
+          out_s[trow] = m;
+        } else if (MODE == FWD_EVAL) {
           // src/metrics.cc:104-105: double predict, -log p / -log(1-p)
           const double pd = 1.0f / (1 + exp(-(double)clamp35(m)));
           out_s[trow] = (float)pd;
@@ -425,6 +432,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
           const float loss = log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f));
           const float res = 1.0f / (1.0f + expf(-m)) - t;
           out_s[trow] = res;
+          out2_s[trow] = m;
           my_r = (unsigned long long)(long long)(res * a.scale);
           acc0 += (double)loss;
           acc1 += (double)res;
@@ -484,7 +492,10 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
 #undef FW_TILE_HEAD
   if (producer && nmine > 0) {
     const uint64_t ptile = tile_of(nmine - 1);
-    if (ptid < tile_rows(ptile)) a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
+    if (ptid < tile_rows(ptile)) {
+      a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
+      if (MODE == FWD_LBFGS && a.out2) a.out2[a.r0 + ptile * rpt + ptid] = out2_s[ptid];
+    }
   }
   if (colsums) {
     __syncthreads();
@@ -560,7 +571,7 @@ __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, cons
 }
 
 int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
-                   float *out_rows, int *nblocks_out) {
+                   float *out_rows, int *nblocks_out, float *margins_out) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(nw >= 1 && nw <= 4, "forward sweep: 1..4 weight vectors, got %d", nw);
   ADMM_REQUIRE(r0 <= r1 && r1 <= csr->nrows, "forward sweep: bad row range");
@@ -581,7 +592,7 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
     a.hmask = csr->d_hmask;
     a.hwarm = csr->d_hwarm;
     a.perm = csr->d_perm;
-    if (mode != FWD_EVAL) {
+    if (mode != FWD_EVAL && mode != FWD_MARGIN) {
       ADMM_REQUIRE(csr->has_t, "forward sweep: the training forms need admm_csr_build_transposed");
       a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
       a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
@@ -594,6 +605,7 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.w[0] = csr->d_wsum;
   a.nw = 1;
   a.out = out_rows;
+  a.out2 = margins_out;
   a.partials = ctx->d_partials;
   a.mode = (int)mode;
   a.nhot = (uint32_t)std::min<uint64_t>(kFwHot, csr->dim);
@@ -605,7 +617,9 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
                            reinterpret_cast<const void *>(&k_forward<FWD_FTRL, true>),
                            reinterpret_cast<const void *>(&k_forward<FWD_EVAL, false>),
                            reinterpret_cast<const void *>(&k_forward<FWD_LBFGS, false>),
-                           reinterpret_cast<const void *>(&k_forward<FWD_FTRL, false>)})
+                           reinterpret_cast<const void *>(&k_forward<FWD_FTRL, false>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_MARGIN, true>),
+                           reinterpret_cast<const void *>(&k_forward<FWD_MARGIN, false>)})
       ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds));
     raised = true;
   }
@@ -629,6 +643,8 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
     FW_LAUNCH(FWD_EVAL)
   } else if (mode == FWD_LBFGS) {
     FW_LAUNCH(FWD_LBFGS)
+  } else if (mode == FWD_MARGIN) {
+    FW_LAUNCH(FWD_MARGIN)
   } else {
     FW_LAUNCH(FWD_FTRL)
   }
@@ -886,14 +902,47 @@ static int fetch_scalars(admm_ctx *ctx, int count) {
   return ADMM_OK;
 }
 
+// One trial point of the line search evaluated from the margins: with m0 = X(x+offset) and
+// md = X d per row, the loss part of the objective at x + s d is the sum over rows of
+// loss(m0 + s md), and its slope along d the sum of (sigma(m0 + s md) - t) md.  Same per-row
+// formulas as the forward sweep's L-BFGS epilogue.
+__global__ void __launch_bounds__(256) k_row_trial(const float *__restrict__ m0, const float *__restrict__ md,
+                                                   const float *__restrict__ label, float step, uint64_t n,
+                                                   double *__restrict__ partials) {
+  __shared__ double sh[2][4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double loss = 0, slope = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float d = md[i];
+    const float m = m0[i] + step * d;
+    const float t = label[i] > 0 ? 1.0f : 0.0f;
+    loss += (double)(log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f)));
+    slope += (double)((1.0f / (1.0f + expf(-m)) - t) * d);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    loss += __shfl_down(loss, off, 64);
+    slope += __shfl_down(slope, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = loss;
+    sh[1][threadIdx.x >> 6] = slope;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[0 * kMaxPartialBlocks + blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    partials[1 * kMaxPartialBlocks + blockIdx.x] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
 static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const float *z, const float *ydual,
-                       float rho, double *f_out, float *g_out) {
+                       float rho, double *f_out, float *g_out, double *loss_out = nullptr,
+                       float *margins_out = nullptr) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(csr->has_t, "admm_logistic_fg: call admm_csr_build_transposed first");
   ADMM_TRY(ensure_rowbuf(csr));
   const float *w[2] = {x, offset};
   int nblk = 0;
-  ADMM_TRY(launch_forward(csr, FWD_LBFGS, 0, csr->nrows, w, offset ? 2 : 1, csr->d_rowbuf, &nblk));
+  ADMM_TRY(launch_forward(csr, FWD_LBFGS, 0, csr->nrows, w, offset ? 2 : 1, csr->d_rowbuf, &nblk, margins_out));
   ADMM_TRY(reduce_rows(ctx, 0, 2, nblk));
   ADMM_TRY(launch_transposed(csr, false, 0, csr->npanels));
   const int grid = grid_for(csr->dim, 256, ctx->cu_count * 8);
@@ -907,6 +956,7 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
   if (f_out) {
     ADMM_TRY(fetch_scalars(ctx, 3));
     *f_out = ctx->h_scalars[0] + ctx->h_scalars[2];
+    if (loss_out) *loss_out = ctx->h_scalars[0];
   }
   return ADMM_OK;
 }
@@ -1086,9 +1136,11 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
                                 float rho, const admm_lbfgs_params *params, admm_lbfgs_result *result) {
   ADMM_REQUIRE(csr && x, "admm_lbfgs_solve: NULL argument");
   admm_ctx *ctx = csr->ctx;
-  admm_lbfgs_params P = {6, 10, 20, 1e-5f, 1e-4f, 0.9f};
+  admm_lbfgs_params P = {6, 10, 20, 1e-5f, 1e-4f, 0.9f, 0};
   if (params) P = *params;
   ADMM_REQUIRE(P.m >= 1 && P.m <= 32 && P.max_iter >= 0 && P.max_linesearch >= 1, "admm_lbfgs_solve: bad params");
+  ADMM_REQUIRE(P.linesearch == 0 || P.linesearch == 1, "admm_lbfgs_solve: linesearch must be 0 or 1, got %d", P.linesearch);
+  const bool from_margins = P.linesearch == 0;
   const uint64_t dim = csr->dim;
   const uint64_t need = (uint64_t)(4 + 2 * P.m) * dim;
   if (ctx->lbfgs_ws_floats < need) {
@@ -1099,15 +1151,41 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     ADMM_HIP_CHECK(hipMalloc(&ctx->lbfgs_ws, sizeof(float) * need));
     ctx->lbfgs_ws_floats = need;
   }
+  if (from_margins && csr->nrows) {
+    if (!csr->d_margin) ADMM_HIP_CHECK(hipMalloc(&csr->d_margin, sizeof(float) * csr->nrows));
+    if (!csr->d_dmargin) ADMM_HIP_CHECK(hipMalloc(&csr->d_dmargin, sizeof(float) * csr->nrows));
+  }
   float *g = ctx->lbfgs_ws, *xp = g + dim, *gp = xp + dim, *d = gp + dim;
   float *S = d + dim, *Y = S + (uint64_t)P.m * dim;
   std::vector<double> ys_hist(P.m, 0.0), alpha(P.m, 0.0);
   int head = 0, count = 0;  // ring: newest at (head-1) mod m
 
-  double f = 0, xx = 0, gg = 0;
-  int evals = 0, iters = 0;
-  ADMM_TRY(logistic_fg(csr, x, offset, z, ydual, rho, &f, g));
-  evals = 1;
+  double f = 0, loss = 0, xx = 0, gg = 0;
+  int evals = 0, iters = 0, fwd_sweeps = 0, tr_sweeps = 0;
+  // a full evaluation: objective, gradient, and (for the line search from the margins) the margins
+  auto full_eval = [&](bool new_point) -> int {
+    ADMM_TRY(logistic_fg(csr, x, offset, z, ydual, rho, &f, g, &loss, from_margins ? csr->d_margin : nullptr));
+    if (new_point) ++evals;
+    ++fwd_sweeps;
+    ++tr_sweeps;
+    return ADMM_OK;
+  };
+  // loss part of the objective and its slope along d at step s, from the margins
+  auto row_trial = [&](double s, double *loss_s, double *slope_s) -> int {
+    const int grid = grid_for(csr->nrows, 256, ctx->cu_count * 8);
+    {
+      KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+      hipLaunchKernelGGL(k_row_trial, dim3(grid), dim3(256), 0, ctx->stream, csr->d_margin, csr->d_dmargin, csr->d_label,
+                         (float)s, csr->nrows, ctx->d_partials);
+      ADMM_HIP_CHECK(hipGetLastError());
+    }
+    ADMM_TRY(reduce_rows(ctx, 0, 2, grid));
+    ADMM_TRY(fetch_scalars(ctx, 2));
+    *loss_s = ctx->h_scalars[0];
+    *slope_s = ctx->h_scalars[1];
+    return ADMM_OK;
+  };
+  ADMM_TRY(full_eval(true));
   ADMM_TRY(vec_dot(ctx, x, x, dim, &xx));
   ADMM_TRY(vec_dot(ctx, g, g, dim, &gg));
   auto done = [&]() {
@@ -1115,6 +1193,8 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       result->f = f;
       result->evals = evals;
       result->iters = iters;
+      result->forward_sweeps = fwd_sweeps;
+      result->transposed_sweeps = tr_sweeps;
     }
     return ADMM_OK;
   };
@@ -1124,24 +1204,48 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   for (int it = 0; it < P.max_iter; ++it) {
     ADMM_TRY(admm_vec_copy(ctx, xp, x, dim));
     ADMM_TRY(admm_vec_copy(ctx, gp, g, dim));
-    const double fp = f;
+    const double fp = f, lossp = loss;
     double dginit = 0;
     ADMM_TRY(vec_dot(ctx, g, d, dim, &dginit));
     if (dginit > 0) break;
     const double dgtest = P.ftol * dginit;
+    // Along x + s d the margins are m0 + s X d and the rest of the objective (the dual term and the
+    // proximal term) is a quadratic in s: reg(s) = reg(0) + s A + s^2 B with A = g.d - (slope of the
+    // loss at 0) and B = rho/2 d.d.  One forward sweep for X d then serves every trial point.
+    double lin = 0, quad = 0;
+    if (from_margins) {
+      const float *wd[1] = {d};
+      int nblk = 0;
+      ADMM_TRY(launch_forward(csr, FWD_MARGIN, 0, csr->nrows, wd, 1, csr->d_dmargin, &nblk));
+      ++fwd_sweeps;
+      double loss0 = 0, slope0 = 0, dd = 0;
+      ADMM_TRY(row_trial(0.0, &loss0, &slope0));
+      ADMM_TRY(vec_dot(ctx, d, d, dim, &dd));
+      lin = dginit - slope0;
+      quad = 0.5 * (double)rho * dd;
+    }
     int ls = 0;
     bool ok = false;
     for (;;) {
-      ADMM_TRY(vec_lincomb(ctx, x, xp, (float)step, d, dim));
-      ADMM_TRY(logistic_fg(csr, x, offset, z, ydual, rho, &f, g));
-      ++evals;
+      double dg = 0;
+      bool have_dg = false;
+      if (from_margins) {
+        double loss_s = 0, slope_s = 0;
+        ADMM_TRY(row_trial(step, &loss_s, &slope_s));
+        ++evals;
+        f = loss_s + (fp - lossp) + step * lin + step * step * quad;
+        dg = slope_s + lin + 2.0 * step * quad;
+        have_dg = true;
+      } else {
+        ADMM_TRY(vec_lincomb(ctx, x, xp, (float)step, d, dim));
+        ADMM_TRY(full_eval(true));
+      }
       ++ls;
       double width;
       if (f > fp + step * dgtest) {
         width = 0.5;
       } else {
-        double dg = 0;
-        ADMM_TRY(vec_dot(ctx, g, d, dim, &dg));
+        if (!have_dg) ADMM_TRY(vec_dot(ctx, g, d, dim, &dg));
         if (dg < P.wolfe * dginit) {
           width = 2.1;
         } else {
@@ -1152,7 +1256,16 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       if (ls >= P.max_linesearch) break;
       step *= width;
     }
-    if (!ok) {
+    if (from_margins) {
+      // x and g still hold the iterate the search started from; move only to a point that is no worse
+      if (ok || f <= fp) {
+        ADMM_TRY(vec_lincomb(ctx, x, xp, (float)step, d, dim));
+        ADMM_TRY(full_eval(false));  // exact objective, gradient and margins at the accepted trial point
+      } else {
+        f = fp;
+      }
+      if (!ok) break;
+    } else if (!ok) {
       if (f > fp) {
         ADMM_TRY(admm_vec_copy(ctx, x, xp, dim));
         ADMM_TRY(admm_vec_copy(ctx, g, gp, dim));

@@ -28,7 +28,7 @@ class AdmmConfig:
         self.global_l1 = 0.0
         self.local_solver = "ftrl"
         self.ftrl_batch = 1
-        self.lbfgs = dict(m=6, max_iter=10, max_linesearch=20, epsilon=1e-5, ftol=1e-4, wolfe=0.9)
+        self.lbfgs = dict(m=6, max_iter=10, max_linesearch=20, epsilon=1e-5, ftol=1e-4, wolfe=0.9, linesearch=0)
 
 
 class FtrlConfig:
@@ -94,7 +94,7 @@ class ArgParser:
             admm_params.local_solver = d["local_solver"]
         if "ftrl_batch" in d:
             admm_params.ftrl_batch = max(1, _atoi(d["ftrl_batch"]))
-        for k in ("m", "max_iter", "max_linesearch"):
+        for k in ("m", "max_iter", "max_linesearch", "linesearch"):
             if "lbfgs_" + k in d:
                 admm_params.lbfgs[k] = _atoi(d["lbfgs_" + k])
         for k in ("epsilon", "ftol", "wolfe"):

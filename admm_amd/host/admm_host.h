@@ -109,7 +109,7 @@ class AdmmConfig {
   real_t global_l1 = 0;                // soft threshold of the consensus update
   std::string local_solver = "ftrl";   // ftrl | lbfgs
   uint64_t ftrl_batch = 1;             // 1 = the reference's row-by-row FTRL
-  admm_lbfgs_params lbfgs = {6, 10, 20, 1e-5f, 1e-4f, 0.9f};
+  admm_lbfgs_params lbfgs = {6, 10, 20, 1e-5f, 1e-4f, 0.9f, 0};
 };
 
 class FtrlConfig {
@@ -226,7 +226,7 @@ class Worker {
   void GetWeights(AdmmConfig &admm_params, DeviceVector &out) const;
   // resident training parts (parsed once, not once per iteration as the reference does)
   std::vector<std::unique_ptr<SampleSet>> parts_;
-  admm_lbfgs_result last_solve_ = {0, 0, 0};
+  admm_lbfgs_result last_solve_ = {0, 0, 0, 0, 0};
 
   std::string psid_;
   int num_part_ = 1;

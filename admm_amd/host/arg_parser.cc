@@ -61,6 +61,7 @@ void ArgParser::ADMMParse(const char *file, AdmmConfig &p) {
   if (d.count("lbfgs_epsilon")) p.lbfgs.epsilon = (float)std::atof(d["lbfgs_epsilon"].c_str());
   if (d.count("lbfgs_ftol")) p.lbfgs.ftol = (float)std::atof(d["lbfgs_ftol"].c_str());
   if (d.count("lbfgs_wolfe")) p.lbfgs.wolfe = (float)std::atof(d["lbfgs_wolfe"].c_str());
+  if (d.count("lbfgs_linesearch")) p.lbfgs.linesearch = std::atoi(d["lbfgs_linesearch"].c_str());
   if (d.count("load_path")) load_path = d["load_path"];
 }
 

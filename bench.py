@@ -39,11 +39,15 @@ def parse_args():
     ap.add_argument("--mean-nnz", type=float, default=131.0,
                     help="feature draws per row; ~99 stay after de-duplication at 2^22 features, +1 bias")
     ap.add_argument("--lbfgs-iters", type=int, default=3)
+    ap.add_argument("--linesearch", type=int, default=0, choices=[0, 1],
+                    help="0: trial points of the line search from the margins (default), 1: by full sweeps")
     ap.add_argument("--panel-rows", type=int, default=0)
     ap.add_argument("--col-block", type=int, default=16384)
     ap.add_argument("--test-frac", type=float, default=0.01)
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-linesearch", action="store_true",
+                    help="skip the two extra iterations that time the other line search mode")
     ap.add_argument("--seed", type=int, default=20251111)
     ap.add_argument("--explicit-values", action="store_true",
                     help="store the generated values (all 1.0) as an f32 array instead of keeping the set as "
@@ -122,7 +126,7 @@ def main():
     prm = driver.AdmmConfig()
     prm.step_size, prm.global_var, prm.global_l1 = 0.01, 4.0, 0.01     # script/start.sh:25-27
     prm.dim, prm.local_solver = args.dim, "lbfgs"
-    prm.lbfgs.update(max_iter=args.lbfgs_iters)
+    prm.lbfgs.update(max_iter=args.lbfgs_iters, linesearch=args.linesearch)
     worker = driver.Worker(ctx)
     worker.InitWorker(args.dim)
     master = driver.Master(ctx)
@@ -146,23 +150,49 @@ def main():
     barrier()
     ctx.timing_enable(True)
     ctx.timing_reset()
-    evals = 0
+    evals = fwd_sweeps = tr_sweeps = 0
     t0 = time.perf_counter()
     last_rec = None
     for _ in range(args.steps):
         last_rec = step()
-        evals += last_rec["stats"]["evals"]
+        st = last_rec["stats"]
+        evals += st["evals"]
+        fwd_sweeps += st.get("forward_sweeps", st["evals"])
+        tr_sweeps += st.get("transposed_sweeps", st["evals"])
     barrier()
     dt = time.perf_counter() - t0
     fwd_ms, fwd_n = ctx.timing_get(capi.K_FORWARD)
     tr_ms, tr_n = ctx.timing_get(capi.K_TRANSPOSED)
     ctx.timing_enable(False)
 
+    # Beside the timed region: two more ADMM iterations with the other line search (every trial
+    # point a full forward + transposed sweep pair), so that the line shows the sweep throughput in
+    # the one-pair-per-evaluation mix as well.  Not part of `value`.
+    other = None
+    if not args.no_other_linesearch:
+        prm.lbfgs["linesearch"] = 1 - args.linesearch
+        step()
+        barrier()
+        o_sweeps, o_t0 = 0.0, time.perf_counter()
+        for _ in range(2):
+            st = step()["stats"]
+            o_sweeps += 0.5 * (st.get("forward_sweeps", st["evals"]) + st.get("transposed_sweeps", st["evals"]))
+        barrier()
+        o_dt = time.perf_counter() - o_t0
+        prm.lbfgs["linesearch"] = args.linesearch
+        o = adist.allreduce_sum_(torch.tensor([float(train.nnz) * o_sweeps], dtype=torch.float64, device="cuda"))
+        o_dt = float(adist.allreduce_max_(torch.tensor([o_dt], dtype=torch.float64, device="cuda")).item())
+        other = {"line_search": "by full sweeps" if args.linesearch == 0 else "from margins",
+                 "ms_per_step": o_dt / 2 * 1e3, "nnz_per_s": float(o.item()) / o_dt, "steps": 2}
+
     # max time and total swept entries over ranks
-    swept = float(train.nnz) * evals
+    # entries swept: every sweep of the sample set counts its stored entries once, so a forward +
+    # transposed pair (one objective/gradient evaluation) counts them twice over two: nnz per pair
+    swept = float(train.nnz) * 0.5 * (fwd_sweeps + tr_sweeps)
     dt = float(adist.allreduce_max_(torch.tensor([dt], dtype=torch.float64, device="cuda")).item())
-    s = adist.allreduce_sum_(torch.tensor([swept, float(train.nnz), float(evals)], dtype=torch.float64, device="cuda"))
-    swept, nnz_total, evals_total = (float(v) for v in s.tolist())
+    s = adist.allreduce_sum_(torch.tensor([swept, float(train.nnz), float(evals), float(fwd_sweeps), float(tr_sweeps)],
+                                          dtype=torch.float64, device="cuda"))
+    swept, nnz_total, evals_total, fwd_total, tr_total = (float(v) for v in s.tolist())
 
     if rank == 0:
         rows = r1 - r0
@@ -212,12 +242,15 @@ def main():
             "config": {
                 "workload": "ADMM-LR L1+L2, synthetic %d rows x %d features, ~%d nnz/row, row-sharded over %d GPU(s)"
                             % (rows_total, args.dim, round(nnz_total / rows_total), world),
-                "local_solver": "lbfgs (max_iter %d)" % args.lbfgs_iters,
+                "local_solver": "lbfgs (max_iter %d, line search %s)" % (
+                    args.lbfgs_iters, "from margins" if args.linesearch == 0 else "by full sweeps"),
                 "values": "all 1.0, stored as f32" if args.explicit_values else
                           "all 1.0, implicit (pattern matrix: no value arrays in HBM)",
                 "rows_total": rows_total, "dim": args.dim, "nnz_total": nnz_total,
-                "objective_gradient_evals_total": evals_total,
+                "objective_evals_total": evals_total,
+                "forward_sweeps_total": fwd_total, "transposed_sweeps_total": tr_total,
                 "admm_iterations_per_s": args.steps / dt,
+                "other_line_search": other,
                 "generate_and_build_s": t_gen,
                 "rank0_hbm_bytes": dict(zip(("row_major", "column_block_copy"), train.bytes())),
                 "last_line": driver.format_line("rank0", *last_rec["line"]) if last_rec and last_rec["line"] else None,

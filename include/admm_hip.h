@@ -170,11 +170,16 @@ typedef struct admm_lbfgs_params {
   float epsilon;      /* ||g|| / max(1, ||x||) stop, default 1e-5 */
   float ftol;         /* Armijo, default 1e-4 */
   float wolfe;        /* curvature, default 0.9 */
+  int linesearch;     /* 0 (default): trial points are evaluated from the margins X(x+offset) and
+                         X d, one pass over per-row data each, and only the accepted point takes
+                         a full evaluation; 1: every trial point is a full evaluation */
 } admm_lbfgs_params;
 typedef struct admm_lbfgs_result {
   double f;
-  int evals; /* objective/gradient evaluations = full sweeps of the sample set */
+  int evals; /* objective evaluations, trial points of the line search included */
   int iters;
+  int forward_sweeps;    /* sweeps of the row-major form (X w) */
+  int transposed_sweeps; /* sweeps of the column-block copy (X^T r) */
 } admm_lbfgs_result;
 /* Minimise the objective above over x (in place) with L-BFGS (two-loop recursion, backtracking
  * Armijo + weak Wolfe line search).  params == NULL uses the defaults. */

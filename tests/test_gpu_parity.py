@@ -243,7 +243,9 @@ def test_logistic_fg(ctx, oracle, binary, mean, panel):
     dev.destroy()
 
 
-def test_lbfgs_solve(ctx, oracle):
+@pytest.mark.parametrize("linesearch", [0, 1])
+def test_lbfgs_solve(ctx, oracle, linesearch):
+    """linesearch 0 evaluates trial points from the margins, 1 by full sweeps: same trajectory"""
     dim = 120
     raw = make_synth_csr(1500, dim, 10, seed=43)
     tr = oracle.translate(raw)
@@ -255,14 +257,19 @@ def test_lbfgs_solve(ctx, oracle):
     x_ref, f_ref, _, _ = oracle.lbfgs_solve(np.zeros(dim, np.float32), fg, max_iter=80, epsilon=1e-6)
     dev = upload(ctx, raw, dim).build_transposed(col_block=64)
     x = ctx.vec(dim)
-    res = dev.lbfgs_solve(x, z=ctx.vec(dim), rho=1.0, max_iter=80, epsilon=1e-6)
+    res = dev.lbfgs_solve(x, z=ctx.vec(dim), rho=1.0, max_iter=80, epsilon=1e-6, linesearch=linesearch)
     close(res["f"], f_ref, rtol=1e-6)
     close(x.download(), x_ref, rtol=1e-3, atol=2e-4)   # both converged to the same minimiser
     # and one short run follows the same trajectory step for step
     x_ref, f_ref, ev_ref, it_ref = oracle.lbfgs_solve(np.zeros(dim, np.float32), fg, max_iter=4)
     x.zero()
-    res = dev.lbfgs_solve(x, z=ctx.vec(dim), rho=1.0, max_iter=4)
+    res = dev.lbfgs_solve(x, z=ctx.vec(dim), rho=1.0, max_iter=4, linesearch=linesearch)
     assert (res["evals"], res["iters"]) == (ev_ref, it_ref)
+    if linesearch == 1:
+        assert res["forward_sweeps"] == res["transposed_sweeps"] == ev_ref
+    else:   # one X d sweep per iteration, one full evaluation per accepted point
+        assert res["transposed_sweeps"] == 1 + it_ref
+        assert res["forward_sweeps"] == 1 + 2 * it_ref
     close(res["f"], f_ref)
     close(x.download(), x_ref, rtol=1e-4, atol=1e-6)
     dev.destroy()

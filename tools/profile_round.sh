@@ -13,10 +13,10 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
   python3 "$root/bench.py" --steps 4 --warmup 1 > "$out/bench_line.json" 2> "$out/bench_stats.err"
 echo "stats done"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o pmc -- \
-  python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_fetch_line.json" 2> "$out/pmc_fetch.err"
+  python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_fetch_line.json" 2> "$out/pmc_fetch.err"
 echo "fetch done"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o pmc -- \
-  python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_write_line.json" 2> "$out/pmc_write.err"
+  python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_write_line.json" 2> "$out/pmc_write.err"
 echo "write done"
 # calibration of the 8-byte-per-lane stream: transposed sweep with its gathers switched off
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o pmc -- \
