@@ -39,8 +39,11 @@ def parse_args():
     ap.add_argument("--mean-nnz", type=float, default=131.0,
                     help="feature draws per row; ~99 stay after de-duplication at 2^22 features, +1 bias")
     ap.add_argument("--lbfgs-iters", type=int, default=3)
-    ap.add_argument("--linesearch", type=int, default=0, choices=[0, 1],
-                    help="0: trial points of the line search from the margins (default), 1: by full sweeps")
+    ap.add_argument("--linesearch", type=int, default=1, choices=[0, 1],
+                    help="1 (default here): every trial point of the L-BFGS line search is a full forward + "
+                         "transposed evaluation, the mix the metric is defined on (entries per objective/gradient "
+                         "evaluation); 0: trial points from the per-row margins, the library's default and the "
+                         "faster ADMM iteration, timed beside the timed region as config.other_line_search")
     ap.add_argument("--panel-rows", type=int, default=0)
     ap.add_argument("--col-block", type=int, default=16384)
     ap.add_argument("--test-frac", type=float, default=0.01)
