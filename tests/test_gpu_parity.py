@@ -408,6 +408,21 @@ def test_sweeps_many_tiles_per_workgroup(ctx, oracle, relabel, explicit_values):
     dev.ftrl_pass(w, zz, n, ctx.vec(dim, b), ctx.vec(dim, z), 0.05, 1.0, 0.1, 1.0, batch=100_000)
     for got, ref in ((w, hw), (zz, hz), (n, hn)):
         close(got.download(), ref, rtol=5e-5, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    # L-BFGS: the line search from the margins walks the same points as the one by full sweeps
+    runs = []
+    for mode in (1, 0):
+        xs = ctx.vec(dim, x)
+        res = dev.lbfgs_solve(xs, offset=ctx.vec(dim, b), z=ctx.vec(dim, z), ydual=ctx.vec(dim, b), rho=0.05,
+                              max_iter=3, linesearch=mode)
+        runs.append((res, xs.download()))
+    (r1, x1), (r0, x0) = runs
+    assert (r0["evals"], r0["iters"]) == (r1["evals"], r1["iters"])
+    assert r1["forward_sweeps"] == r1["transposed_sweeps"] == r1["evals"]
+    assert r0["transposed_sweeps"] == 1 + r0["iters"] and r0["forward_sweeps"] == 1 + 2 * r0["iters"]
+    close(r0["f"], r1["f"], rtol=1e-6)
+    close(x0, x1, rtol=1e-4, atol=1e-6)
+    f_ref, _ = oracle.logistic_fg(tr, dim, x0, b, z, b, 0.05)
+    close(r0["f"], f_ref)
     dev.destroy()
 
 
