@@ -405,7 +405,7 @@ static void free_csr(admm_csr *c) {
     hipSetDevice(c->ctx->device);
     hipStreamSynchronize(c->ctx->stream);
   }
-  void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_margin, c->d_dmargin, c->d_tptr,
+  void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_margin, c->d_dmargin, c->d_cache_x, c->d_cache_off, c->d_cache_gl, c->d_tptr,
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol};
   for (void *p : ptrs)
@@ -647,6 +647,7 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
     RL_CHECK(hipStreamSynchronize(ctx->stream));
     csr->hot_dense = true;
   }
+  csr->cache_valid = false;
 #undef RL_CHECK
   // a transposed copy built earlier still holds the entries the mask now covers: rebuild it
   if (csr->has_t && csr->hot_dense) return admm_csr_build_transposed(csr, csr->panel_rows, csr->col_block);
@@ -683,6 +684,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
     *p = nullptr;
   }
   csr->has_t = false;
+  csr->cache_valid = false;
   csr->panel_rows = panel_rows;
   csr->col_block = col_block;
   csr->nblocks = (uint32_t)((csr->dim + col_block - 1) / col_block);

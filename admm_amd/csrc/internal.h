@@ -95,6 +95,11 @@ struct admm_csr {
   float *d_rowbuf = nullptr;  // nrows floats: p / residual / per-row gradient scale
   float *d_margin = nullptr;  // nrows floats each: margins X(x+offset) at the L-BFGS iterate, and X d
   float *d_dmargin = nullptr;
+  // what the last L-BFGS solve ended on: its x and offset (to recognise them), the loss part of the
+  // gradient there and the loss; d_margin belongs to the same point when cache_margin is set
+  float *d_cache_x = nullptr, *d_cache_off = nullptr, *d_cache_gl = nullptr;
+  double cache_loss = 0;
+  bool cache_valid = false, cache_has_off = false, cache_margin = false;
   float *d_wsum = nullptr;    // dim floats: the vector the forward sweep gathers (relabelled order)
   // columns relabelled by decreasing frequency: d_col holds NEW ids; perm: new -> old, inv: old -> new
   uint32_t *d_perm = nullptr, *d_inv = nullptr;

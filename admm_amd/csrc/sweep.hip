@@ -850,20 +850,30 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
 // ---------------------------------------------------------------------------------------------
 
 // g = acc + y + rho (x - z), acc reset to 0; column 0 also receives the bias-column sum the
-// forward sweep produced (scalars[1]); partials row 2 <- y.(x-z) + rho/2 |x-z|^2
+// forward sweep produced (scalars[1]); partials row 2 <- y.(x-z) + rho/2 |x-z|^2.
+// gl_out (optional) keeps the loss part `acc` of the gradient as a float vector; with gl_in the
+// kernel takes that part from such a vector instead of the accumulators (same arithmetic after
+// it, so the result is bit for bit the one of a fresh evaluation at the same x).
 __global__ void __launch_bounds__(256) k_fg_finish(long long *__restrict__ accum, double inv_scale,
                                                    const float *__restrict__ x,
                                                    const float *__restrict__ z, const float *__restrict__ y,
                                                    float rho, const double *__restrict__ scalars, int add_bias,
-                                                   float *__restrict__ g, uint64_t n, double *__restrict__ partials) {
+                                                   float *__restrict__ g, uint64_t n, double *__restrict__ partials,
+                                                   float *__restrict__ gl_out, const float *__restrict__ gl_in) {
   __shared__ double sh[4];
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   double reg = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    double ad = (double)accum[i] * inv_scale;
-    accum[i] = 0;
-    if (add_bias && i == 0) ad += scalars[1];
-    const float a = (float)ad;
+    float a;
+    if (gl_in) {
+      a = gl_in[i];
+    } else {
+      double ad = (double)accum[i] * inv_scale;
+      accum[i] = 0;
+      if (add_bias && i == 0) ad += scalars[1];
+      a = (float)ad;
+      if (gl_out) gl_out[i] = a;
+    }
     const float d = x[i] - (z ? z[i] : 0.0f);
     const float yd = y ? y[i] : 0.0f;
     g[i] = a + yd + rho * d;
@@ -902,6 +912,23 @@ static int fetch_scalars(admm_ctx *ctx, int count) {
   return ADMM_OK;
 }
 
+// number of positions where two vectors (and, when given, two more) differ bit for bit
+__global__ void __launch_bounds__(256) k_count_diff(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                    const uint32_t *__restrict__ c, const uint32_t *__restrict__ d,
+                                                    uint64_t n, double *__restrict__ partials) {
+  __shared__ double sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double diff = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    diff += a[i] != b[i] ? 1.0 : 0.0;
+    if (c) diff += c[i] != d[i] ? 1.0 : 0.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) diff += __shfl_down(diff, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = diff;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[0 * kMaxPartialBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // One trial point of the line search evaluated from the margins: with m0 = X(x+offset) and
 // md = X d per row, the loss part of the objective at x + s d is the sum over rows of
 // loss(m0 + s md), and its slope along d the sum of (sigma(m0 + s md) - t) md.  Same per-row
@@ -936,7 +963,7 @@ __global__ void __launch_bounds__(256) k_row_trial(const float *__restrict__ m0,
 
 static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const float *z, const float *ydual,
                        float rho, double *f_out, float *g_out, double *loss_out = nullptr,
-                       float *margins_out = nullptr) {
+                       float *margins_out = nullptr, float *gl_out = nullptr) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(csr->has_t, "admm_logistic_fg: call admm_csr_build_transposed first");
   ADMM_TRY(ensure_rowbuf(csr));
@@ -949,7 +976,8 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
   {
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
-                       ydual, rho, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, g_out, csr->dim, ctx->d_partials);
+                       ydual, rho, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, g_out, csr->dim, ctx->d_partials,
+                       gl_out, (const float *)nullptr);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
@@ -1160,11 +1188,16 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   std::vector<double> ys_hist(P.m, 0.0), alpha(P.m, 0.0);
   int head = 0, count = 0;  // ring: newest at (head-1) mod m
 
+  for (float **p : {&csr->d_cache_x, &csr->d_cache_off, &csr->d_cache_gl})
+    if (!*p) ADMM_HIP_CHECK(hipMalloc(p, sizeof(float) * dim));
   double f = 0, loss = 0, xx = 0, gg = 0;
   int evals = 0, iters = 0, fwd_sweeps = 0, tr_sweeps = 0;
+  bool gl_at_x = true;  // d_cache_gl is the loss gradient at the current x
   // a full evaluation: objective, gradient, and (for the line search from the margins) the margins
   auto full_eval = [&](bool new_point) -> int {
-    ADMM_TRY(logistic_fg(csr, x, offset, z, ydual, rho, &f, g, &loss, from_margins ? csr->d_margin : nullptr));
+    ADMM_TRY(logistic_fg(csr, x, offset, z, ydual, rho, &f, g, &loss, from_margins ? csr->d_margin : nullptr,
+                         csr->d_cache_gl));
+    gl_at_x = true;
     if (new_point) ++evals;
     ++fwd_sweeps;
     ++tr_sweeps;
@@ -1185,10 +1218,52 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     *slope_s = ctx->h_scalars[1];
     return ADMM_OK;
   };
-  ADMM_TRY(full_eval(true));
+  // An ADMM iteration starts its solve where the previous one ended: same x, same offset, only z and
+  // the dual have moved, and the sweeps do not depend on those.  If x and offset are bit for bit the
+  // ones the last solve on this sample set ended on, its loss and loss gradient are still valid and the
+  // first evaluation costs no sweep.
+  bool from_cache = false;
+  {
+    const char *env = getenv("ADMM_FG_CACHE");
+    if (csr->cache_valid && !(env && env[0] == '0') && csr->cache_has_off == (offset != nullptr) &&
+        (!from_margins || csr->cache_margin)) {
+      const int grid = grid_for(dim, 256, ctx->cu_count * 8);
+      hipLaunchKernelGGL(k_count_diff, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t *>(x),
+                         reinterpret_cast<const uint32_t *>(csr->d_cache_x), reinterpret_cast<const uint32_t *>(offset),
+                         reinterpret_cast<const uint32_t *>(csr->d_cache_off), dim, ctx->d_partials);
+      ADMM_HIP_CHECK(hipGetLastError());
+      ADMM_TRY(reduce_rows(ctx, 0, 1, grid));
+      ADMM_TRY(fetch_scalars(ctx, 1));
+      from_cache = ctx->h_scalars[0] == 0.0;
+    }
+  }
+  csr->cache_valid = false;  // until this solve has ended
+  if (from_cache) {
+    const int grid = grid_for(dim, 256, ctx->cu_count * 8);
+    hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, (long long *)nullptr, 0.0, x, z, ydual, rho,
+                       ctx->d_scalars, 0, g, dim, ctx->d_partials, (float *)nullptr, (const float *)csr->d_cache_gl);
+    ADMM_HIP_CHECK(hipGetLastError());
+    ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
+    ADMM_TRY(fetch_scalars(ctx, 3));
+    loss = csr->cache_loss;
+    f = loss + ctx->h_scalars[2];
+    ++evals;
+  } else {
+    ADMM_TRY(full_eval(true));
+  }
   ADMM_TRY(vec_dot(ctx, x, x, dim, &xx));
   ADMM_TRY(vec_dot(ctx, g, g, dim, &gg));
-  auto done = [&]() {
+  auto done = [&]() -> int {
+    // remember where this solve ended
+    if (gl_at_x) {
+      ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_cache_x, x, sizeof(float) * dim, hipMemcpyDeviceToDevice, ctx->stream));
+      if (offset)
+        ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_cache_off, offset, sizeof(float) * dim, hipMemcpyDeviceToDevice, ctx->stream));
+      csr->cache_has_off = offset != nullptr;
+      csr->cache_loss = loss;
+      csr->cache_margin = from_margins;
+      csr->cache_valid = true;
+    }
     if (result) {
       result->f = f;
       result->evals = evals;
@@ -1270,6 +1345,8 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
         ADMM_TRY(admm_vec_copy(ctx, x, xp, dim));
         ADMM_TRY(admm_vec_copy(ctx, g, gp, dim));
         f = fp;
+        loss = lossp;
+        gl_at_x = false;  // the kept loss gradient belongs to the rejected trial point
       }
       break;
     }

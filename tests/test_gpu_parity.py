@@ -275,6 +275,40 @@ def test_lbfgs_solve(ctx, oracle, linesearch):
     dev.destroy()
 
 
+@pytest.mark.parametrize("linesearch", [0, 1])
+def test_lbfgs_warm_start_reuses_the_last_evaluation(ctx, linesearch, monkeypatch):
+    """a solve that starts where the previous one on the same set ended (same x and offset; z and the
+    dual moved, as between ADMM iterations) takes its first loss and loss gradient from that solve:
+    one sweep pair fewer, bit-identical results"""
+    dim = 5000
+    raw = make_synth_csr(4000, dim, 20, seed=7)
+    rng = np.random.default_rng(3)
+    off = rng.normal(0, 0.05, dim).astype(np.float32)
+    z1 = rng.normal(0, 0.1, dim).astype(np.float32)
+    z2 = rng.normal(0, 0.1, dim).astype(np.float32)
+    y2 = rng.normal(0, 0.01, dim).astype(np.float32)
+    out = {}
+    for cache in ("1", "0"):
+        monkeypatch.setenv("ADMM_FG_CACHE", cache)
+        dev = upload(ctx, raw, dim).build_transposed(col_block=1024).relabel_by_frequency()
+        x = ctx.vec(dim)
+        first = dev.lbfgs_solve(x, offset=ctx.vec(dim, off), z=ctx.vec(dim, z1), rho=0.5, max_iter=3, linesearch=linesearch)
+        second = dev.lbfgs_solve(x, offset=ctx.vec(dim, off), z=ctx.vec(dim, z2), ydual=ctx.vec(dim, y2), rho=0.5,
+                                 max_iter=3, linesearch=linesearch)
+        # a different offset must not be served from the cache
+        third = dev.lbfgs_solve(x, offset=ctx.vec(dim, 2 * off), z=ctx.vec(dim, z2), rho=0.5, max_iter=2,
+                                linesearch=linesearch)
+        out[cache] = (first, second, third, x.download())
+        dev.destroy()
+    (f1, s1, t1, x1), (f0, s0, t0, x0) = out["1"], out["0"]
+    np.testing.assert_array_equal(x1, x0)
+    for a_, b_ in ((f1, f0), (s1, s0), (t1, t0)):
+        assert (a_["f"], a_["evals"], a_["iters"]) == (b_["f"], b_["evals"], b_["iters"])
+    assert f1["forward_sweeps"] == f0["forward_sweeps"] and t1["forward_sweeps"] == t0["forward_sweeps"]
+    assert s1["forward_sweeps"] == s0["forward_sweeps"] - 1
+    assert s1["transposed_sweeps"] == s0["transposed_sweeps"] - 1
+
+
 # ------------------------------------------------------------------------------------------------
 # consensus algebra
 # ------------------------------------------------------------------------------------------------
