@@ -309,6 +309,31 @@ def test_lbfgs_warm_start_reuses_the_last_evaluation(ctx, linesearch, monkeypatc
     assert s1["transposed_sweeps"] == s0["transposed_sweeps"] - 1
 
 
+@pytest.mark.parametrize("linesearch", [0, 1])
+@pytest.mark.parametrize("nrows", [0, 1, 3])
+def test_lbfgs_on_tiny_sets(ctx, oracle, nrows, linesearch):
+    """no rows (only the proximal term is left), one row, and a handful: the solve runs and agrees
+    with the oracle's solver"""
+    dim = 300
+    raw = make_synth_csr(nrows, dim, 6, seed=5)
+    tr = oracle.translate(raw)
+    z = np.full(dim, 0.25, np.float32)
+
+    def fg(xx):
+        return oracle.logistic_fg(tr, dim, xx, None, z, None, 2.0)
+
+    x_ref, f_ref, ev_ref, it_ref = oracle.lbfgs_solve(np.zeros(dim, np.float32), fg, max_iter=5)
+    dev = upload(ctx, raw, dim).build_transposed(col_block=128)
+    if nrows:
+        dev.relabel_by_frequency()
+    x = ctx.vec(dim)
+    res = dev.lbfgs_solve(x, z=ctx.vec(dim, z), rho=2.0, max_iter=5, linesearch=linesearch)
+    assert (res["evals"], res["iters"]) == (ev_ref, it_ref)
+    close(res["f"], f_ref, atol=1e-6)
+    close(x.download(), x_ref, rtol=1e-4, atol=1e-6)
+    dev.destroy()
+
+
 # ------------------------------------------------------------------------------------------------
 # consensus algebra
 # ------------------------------------------------------------------------------------------------
