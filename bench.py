@@ -78,7 +78,7 @@ def cpu_baseline(ctx, args, rho):
         x = (x - np.float32(1e-4) * g.astype(np.float32)).astype(np.float32)
         evals += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or evals >= 8:
+        if dt > 12.0 or evals >= 48:   # about 12 s of CPU work
             break
     fg_rate = csr.nnz * evals / dt
     # the reference's own local solver on the same sample: one sequential FTRL pass
