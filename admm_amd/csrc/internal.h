@@ -100,6 +100,7 @@ struct admm_csr {
   float *d_cache_x = nullptr, *d_cache_off = nullptr, *d_cache_gl = nullptr;
   double cache_loss = 0;
   bool cache_valid = false, cache_has_off = false, cache_margin = false;
+  int margin_age = 0;  // accepted steps added to d_margin since a forward sweep last recomputed it
   float *d_wsum = nullptr;    // dim floats: the vector the forward sweep gathers (relabelled order)
   // columns relabelled by decreasing frequency: d_col holds NEW ids; perm: new -> old, inv: old -> new
   uint32_t *d_perm = nullptr, *d_inv = nullptr;

@@ -961,6 +961,97 @@ __global__ void __launch_bounds__(256) k_row_trial(const float *__restrict__ m0,
   }
 }
 
+// The accepted point of a line search from the margins: m0 <- m0 + s md, and what the forward
+// sweep's L-BFGS epilogue would have written for those margins (residual per row, loss and
+// residual sums).  Same per-row arithmetic as k_row_trial, so the loss equals the trial's.
+__global__ void __launch_bounds__(256) k_row_accept(float *__restrict__ m0, const float *__restrict__ md,
+                                                    const float *__restrict__ label, float step, uint64_t n,
+                                                    float *__restrict__ res_out, double *__restrict__ partials) {
+  __shared__ double sh[2][4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double loss = 0, rsum = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float m = m0[i] + step * md[i];
+    m0[i] = m;
+    const float t = label[i] > 0 ? 1.0f : 0.0f;
+    const float res = 1.0f / (1.0f + expf(-m)) - t;
+    res_out[i] = res;
+    loss += (double)(log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f)));
+    rsum += (double)res;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    loss += __shfl_down(loss, off, 64);
+    rsum += __shfl_down(rsum, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = loss;
+    sh[1][threadIdx.x >> 6] = rsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[0 * kMaxPartialBlocks + blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    partials[1 * kMaxPartialBlocks + blockIdx.x] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+// X^T r restricted to the kMaskCols columns that a compact set keeps as per-row bit masks, from the
+// residuals in memory (the forward sweep adds these sums itself when it computes the residuals).
+// One wave takes 64 rows at a time, a row per lane.  Columns 0..63 are dense: the wave walks its
+// rows, broadcasts a row's mask and fixed-point residual, and lane k adds the residual when bit k
+// is set.  Columns 64.. are sparse: each lane walks the set bits of its own row and adds to
+// per-column LDS accumulators.  Same 64-bit fixed point as everywhere else: order-independent.
+__global__ void __launch_bounds__(256) k_mask_colsums(const unsigned long long *__restrict__ hmask,
+                                                      const unsigned long long *__restrict__ hwarm,
+                                                      const float *__restrict__ res, uint64_t nrows, float scale,
+                                                      const uint32_t *__restrict__ perm,
+                                                      unsigned long long *__restrict__ g1) {
+  __shared__ unsigned long long acc[kMaskCols];
+  const int tid = threadIdx.x, lane = tid & 63;
+  acc[tid] = 0ull;
+  static_assert(kMaskCols == 256, "one accumulator per thread");
+  __syncthreads();
+  unsigned long long h = 0;  // lane k: column k over the rows this wave has seen
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4, wave = (uint64_t)blockIdx.x * 4 + (tid >> 6);
+  auto bcast = [](unsigned long long v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  for (uint64_t base = wave * 64; base < nrows; base += nwaves * 64) {
+    const uint64_t r = base + lane;
+    const bool on = r < nrows;
+    const unsigned long long m0 = on ? hmask[r] : 0ull;
+    const unsigned long long rv = on ? (unsigned long long)(long long)(res[r] * scale) : 0ull;
+    unsigned long long mw[kWarmWords];
+#pragma unroll
+    for (int w = 0; w < kWarmWords; ++w) mw[w] = on ? hwarm[r * kWarmWords + w] : 0ull;
+    // dense word: four rows per trip, independent partial sums
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      p0 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, k)) ? bcast(rv, k) : 0ull;
+      p1 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, k + 1)) ? bcast(rv, k + 1) : 0ull;
+      p2 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, k + 2)) ? bcast(rv, k + 2) : 0ull;
+      p3 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, k + 3)) ? bcast(rv, k + 3) : 0ull;
+    }
+    h += (p0 + p1) + (p2 + p3);
+    // sparse words: the three words of a row are walked together
+    while (mw[0] | mw[1] | mw[2]) {
+#pragma unroll
+      for (int w = 0; w < kWarmWords; ++w) {
+        if (mw[w]) {
+          atomicAdd(&acc[64 * (w + 1) + __builtin_ctzll(mw[w])], rv);
+          mw[w] &= mw[w] - 1;
+        }
+      }
+    }
+  }
+  static_assert(kWarmWords == 3, "the walk above names three words");
+  if (h) atomicAdd(&acc[lane], h);
+  __syncthreads();
+  if (acc[tid]) atomicAdd(g1 + perm[tid], acc[tid]);
+}
+
 static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const float *z, const float *ydual,
                        float rho, double *f_out, float *g_out, double *loss_out = nullptr,
                        float *margins_out = nullptr, float *gl_out = nullptr) {
@@ -1167,8 +1258,9 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   admm_lbfgs_params P = {6, 10, 20, 1e-5f, 1e-4f, 0.9f, 0};
   if (params) P = *params;
   ADMM_REQUIRE(P.m >= 1 && P.m <= 32 && P.max_iter >= 0 && P.max_linesearch >= 1, "admm_lbfgs_solve: bad params");
-  ADMM_REQUIRE(P.linesearch == 0 || P.linesearch == 1, "admm_lbfgs_solve: linesearch must be 0 or 1, got %d", P.linesearch);
-  const bool from_margins = P.linesearch == 0;
+  ADMM_REQUIRE(P.linesearch >= 0 && P.linesearch <= 2, "admm_lbfgs_solve: linesearch must be 0, 1 or 2, got %d", P.linesearch);
+  const bool from_margins = P.linesearch != 1;
+  const bool cheap_accept = P.linesearch == 2;
   const uint64_t dim = csr->dim;
   const uint64_t need = (uint64_t)(4 + 2 * P.m) * dim;
   if (ctx->lbfgs_ws_floats < need) {
@@ -1198,6 +1290,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     ADMM_TRY(logistic_fg(csr, x, offset, z, ydual, rho, &f, g, &loss, from_margins ? csr->d_margin : nullptr,
                          csr->d_cache_gl));
     gl_at_x = true;
+    if (from_margins) csr->margin_age = 0;
     if (new_point) ++evals;
     ++fwd_sweeps;
     ++tr_sweeps;
@@ -1251,6 +1344,52 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   } else {
     ADMM_TRY(full_eval(true));
   }
+  // The accepted point of a line search from the margins without a forward sweep: the margins
+  // there are m0 + s md, so the residuals, the loss and the mask columns' sums come from per-row
+  // passes, and only the transposed sweep is left.  The margins pick up one float rounding per
+  // such step, so after two of them (and at the last iteration of a solve, whose margins the next
+  // solve may start from) the accepted point takes a full evaluation again.  The gradient differs
+  // from a full evaluation's in its last bits, which a long ADMM run amplifies (1e-4 relative in the
+  // test logloss after five iterations at 100M rows), hence a mode of its own.
+  auto accept_from_margins = [&](double s) -> int {
+    ADMM_TRY(ensure_rowbuf(csr));
+    const int rgrid = grid_for(csr->nrows, 256, ctx->cu_count * 8);
+    {
+      KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+      hipLaunchKernelGGL(k_row_accept, dim3(rgrid), dim3(256), 0, ctx->stream, csr->d_margin, csr->d_dmargin, csr->d_label,
+                         (float)s, csr->nrows, csr->d_rowbuf, ctx->d_partials);
+      ADMM_HIP_CHECK(hipGetLastError());
+    }
+    ADMM_TRY(reduce_rows(ctx, 0, 2, rgrid));
+    if (csr->hot_dense) {
+      ADMM_TRY(ensure_taccum(csr));
+      const int mgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((csr->nrows + 255) / 256, (uint64_t)ctx->cu_count * 8));
+      KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+      hipLaunchKernelGGL(k_mask_colsums, dim3(mgrid), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<const unsigned long long *>(csr->d_hmask),
+                         reinterpret_cast<const unsigned long long *>(csr->d_hwarm), csr->d_rowbuf,
+                         csr->nrows, std::ldexp(1.0f, csr->fx_shift), csr->d_perm,
+                         reinterpret_cast<unsigned long long *>(csr->d_g1));
+      ADMM_HIP_CHECK(hipGetLastError());
+    }
+    ADMM_TRY(launch_transposed(csr, false, 0, csr->npanels));
+    ++tr_sweeps;
+    const int grid = grid_for(dim, 256, ctx->cu_count * 8);
+    {
+      KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+      hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
+                         ydual, rho, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, g, dim, ctx->d_partials,
+                         csr->d_cache_gl, (const float *)nullptr);
+      ADMM_HIP_CHECK(hipGetLastError());
+    }
+    ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
+    ADMM_TRY(fetch_scalars(ctx, 3));
+    loss = ctx->h_scalars[0];
+    f = loss + ctx->h_scalars[2];
+    gl_at_x = true;
+    ++csr->margin_age;
+    return ADMM_OK;
+  };
   ADMM_TRY(vec_dot(ctx, x, x, dim, &xx));
   ADMM_TRY(vec_dot(ctx, g, g, dim, &gg));
   auto done = [&]() -> int {
@@ -1335,7 +1474,10 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       // x and g still hold the iterate the search started from; move only to a point that is no worse
       if (ok || f <= fp) {
         ADMM_TRY(vec_lincomb(ctx, x, xp, (float)step, d, dim));
-        ADMM_TRY(full_eval(false));  // exact objective, gradient and margins at the accepted trial point
+        if (cheap_accept && ok && it + 1 < P.max_iter && csr->margin_age < 2)
+          ADMM_TRY(accept_from_margins(step));
+        else
+          ADMM_TRY(full_eval(false));  // exact objective, gradient and margins at the accepted trial point
       } else {
         f = fp;
       }

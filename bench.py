@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--mean-nnz", type=float, default=131.0,
                     help="feature draws per row; ~99 stay after de-duplication at 2^22 features, +1 bias")
     ap.add_argument("--lbfgs-iters", type=int, default=3)
-    ap.add_argument("--linesearch", type=int, default=1, choices=[0, 1],
+    ap.add_argument("--linesearch", type=int, default=1, choices=[0, 1, 2],
                     help="1 (default here): every trial point of the L-BFGS line search is a full forward + "
                          "transposed evaluation, the mix the metric is defined on (entries per objective/gradient "
                          "evaluation); 0: trial points from the per-row margins, the library's default and the "
@@ -168,25 +168,30 @@ def main():
     tr_ms, tr_n = ctx.timing_get(capi.K_TRANSPOSED)
     ctx.timing_enable(False)
 
-    # Beside the timed region: two more ADMM iterations with the other line search (every trial
-    # point a full forward + transposed sweep pair), so that the line shows the sweep throughput in
-    # the one-pair-per-evaluation mix as well.  Not part of `value`.
+    # Beside the timed region: two more ADMM iterations in each of the other line search modes (after one
+    # untimed iteration each), so that the line shows what an ADMM iteration costs in the library's default
+    # mode and in the fastest one as well.  Not part of `value`.
     other = None
     if not args.no_other_linesearch:
-        prm.lbfgs["linesearch"] = 1 - args.linesearch
-        step()
-        barrier()
-        o_sweeps, o_t0 = 0.0, time.perf_counter()
-        for _ in range(2):
-            st = step()["stats"]
-            o_sweeps += 0.5 * (st.get("forward_sweeps", st["evals"]) + st.get("transposed_sweeps", st["evals"]))
-        barrier()
-        o_dt = time.perf_counter() - o_t0
+        names = ("from margins", "by full sweeps", "from margins, accepted point too")
+        other = []
+        for mode in (0, 1, 2):
+            if mode == args.linesearch:
+                continue
+            prm.lbfgs["linesearch"] = mode
+            step()
+            barrier()
+            o_sweeps, o_t0 = 0.0, time.perf_counter()
+            for _ in range(2):
+                st = step()["stats"]
+                o_sweeps += 0.5 * (st.get("forward_sweeps", st["evals"]) + st.get("transposed_sweeps", st["evals"]))
+            barrier()
+            o_dt = time.perf_counter() - o_t0
+            o = adist.allreduce_sum_(torch.tensor([float(train.nnz) * o_sweeps], dtype=torch.float64, device="cuda"))
+            o_dt = float(adist.allreduce_max_(torch.tensor([o_dt], dtype=torch.float64, device="cuda")).item())
+            other.append({"line_search": names[mode], "lbfgs_linesearch": mode, "ms_per_step": o_dt / 2 * 1e3,
+                          "nnz_per_s": float(o.item()) / o_dt, "steps": 2})
         prm.lbfgs["linesearch"] = args.linesearch
-        o = adist.allreduce_sum_(torch.tensor([float(train.nnz) * o_sweeps], dtype=torch.float64, device="cuda"))
-        o_dt = float(adist.allreduce_max_(torch.tensor([o_dt], dtype=torch.float64, device="cuda")).item())
-        other = {"line_search": "by full sweeps" if args.linesearch == 0 else "from margins",
-                 "ms_per_step": o_dt / 2 * 1e3, "nnz_per_s": float(o.item()) / o_dt, "steps": 2}
 
     # max time and total swept entries over ranks
     # entries swept: every sweep of the sample set counts its stored entries once, so a forward +
@@ -246,7 +251,7 @@ def main():
                 "workload": "ADMM-LR L1+L2, synthetic %d rows x %d features, ~%d nnz/row, row-sharded over %d GPU(s)"
                             % (rows_total, args.dim, round(nnz_total / rows_total), world),
                 "local_solver": "lbfgs (max_iter %d, line search %s)" % (
-                    args.lbfgs_iters, "from margins" if args.linesearch == 0 else "by full sweeps"),
+                    args.lbfgs_iters, ("from margins", "by full sweeps", "from margins, accepted point too")[args.linesearch]),
                 "values": "all 1.0, stored as f32" if args.explicit_values else
                           "all 1.0, implicit (pattern matrix: no value arrays in HBM)",
                 "rows_total": rows_total, "dim": args.dim, "nnz_total": nnz_total,

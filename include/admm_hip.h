@@ -172,7 +172,11 @@ typedef struct admm_lbfgs_params {
   float wolfe;        /* curvature, default 0.9 */
   int linesearch;     /* 0 (default): trial points are evaluated from the margins X(x+offset) and
                          X d, one pass over per-row data each, and only the accepted point takes
-                         a full evaluation; 1: every trial point is a full evaluation */
+                         a full evaluation; 1: every trial point is a full evaluation; 2: as 0, and the
+                         accepted point is evaluated from the margins too (residuals, loss and the
+                         mask columns' sums by per-row passes, then the transposed sweep), with a
+                         full evaluation every third accepted point and at a solve's last iteration:
+                         fastest, but its iterates differ from modes 0/1 in the last bits */
 } admm_lbfgs_params;
 typedef struct admm_lbfgs_result {
   double f;

@@ -243,7 +243,7 @@ def test_logistic_fg(ctx, oracle, binary, mean, panel):
     dev.destroy()
 
 
-@pytest.mark.parametrize("linesearch", [0, 1])
+@pytest.mark.parametrize("linesearch", [0, 1, 2])
 def test_lbfgs_solve(ctx, oracle, linesearch):
     """linesearch 0 evaluates trial points from the margins, 1 by full sweeps: same trajectory"""
     dim = 120
@@ -267,9 +267,12 @@ def test_lbfgs_solve(ctx, oracle, linesearch):
     assert (res["evals"], res["iters"]) == (ev_ref, it_ref)
     if linesearch == 1:
         assert res["forward_sweeps"] == res["transposed_sweeps"] == ev_ref
-    else:   # one X d sweep per iteration, one full evaluation per accepted point
+    elif linesearch == 0:   # one X d sweep per iteration, one full evaluation per accepted point
         assert res["transposed_sweeps"] == 1 + it_ref
         assert res["forward_sweeps"] == 1 + 2 * it_ref
+    else:   # an accepted point takes a forward sweep only now and then
+        assert res["transposed_sweeps"] == 1 + it_ref
+        assert 1 + it_ref < res["forward_sweeps"] < 1 + 2 * it_ref
     close(res["f"], f_ref)
     close(x.download(), x_ref, rtol=1e-4, atol=1e-6)
     dev.destroy()
@@ -309,7 +312,7 @@ def test_lbfgs_warm_start_reuses_the_last_evaluation(ctx, linesearch, monkeypatc
     assert s1["transposed_sweeps"] == s0["transposed_sweeps"] - 1
 
 
-@pytest.mark.parametrize("linesearch", [0, 1])
+@pytest.mark.parametrize("linesearch", [0, 1, 2])
 @pytest.mark.parametrize("nrows", [0, 1, 3])
 def test_lbfgs_on_tiny_sets(ctx, oracle, nrows, linesearch):
     """no rows (only the proximal term is left), one row, and a handful: the solve runs and agrees
@@ -469,12 +472,17 @@ def test_sweeps_many_tiles_per_workgroup(ctx, oracle, relabel, explicit_values):
         close(got.download(), ref, rtol=5e-5, atol=1e-6 * max(1.0, np.abs(ref).max()))
     # L-BFGS: the line search from the margins walks the same points as the one by full sweeps
     runs = []
-    for mode in (1, 0):
+    for mode in (1, 0, 2):
         xs = ctx.vec(dim, x)
         res = dev.lbfgs_solve(xs, offset=ctx.vec(dim, b), z=ctx.vec(dim, z), ydual=ctx.vec(dim, b), rho=0.05,
                               max_iter=3, linesearch=mode)
         runs.append((res, xs.download()))
-    (r1, x1), (r0, x0) = runs
+    (r1, x1), (r0, x0), (r2, x2) = runs
+    # mode 2: two accepted points from the margins, the last one by a full evaluation
+    assert (r2["evals"], r2["iters"]) == (r1["evals"], r1["iters"])
+    assert r2["transposed_sweeps"] == 1 + r2["iters"] and r2["forward_sweeps"] == 1 + r2["iters"] + 1
+    close(r2["f"], r1["f"], rtol=1e-6)
+    close(x2, x1, rtol=1e-4, atol=1e-6)
     assert (r0["evals"], r0["iters"]) == (r1["evals"], r1["iters"])
     assert r1["forward_sweeps"] == r1["transposed_sweeps"] == r1["evals"]
     assert r0["transposed_sweeps"] == 1 + r0["iters"] and r0["forward_sweeps"] == 1 + 2 * r0["iters"]
