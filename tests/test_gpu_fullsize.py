@@ -72,14 +72,43 @@ def test_gradient_linear_reproducible_and_consistent(big):
     np.testing.assert_allclose(g1 - g2, y + np.float32(0.5) * (x - z), rtol=0, atol=2e-6 * np.abs(g1).max())
 
 
-def test_lbfgs_decreases_objective(big):
+@pytest.mark.parametrize("linesearch", [0, 1, 2])
+def test_lbfgs_decreases_objective(big, linesearch):
+    """every line search mode lowers the objective, reports the objective of the point it returns,
+    and (two solves in a row, as two ADMM iterations) restarts from its own last evaluation"""
     ctx, s = big
     x, g = ctx.vec(DIM), ctx.vec(DIM)
     f_start = s.logistic_fg(x, g, rho=0.01)
     assert f_start == pytest.approx(ROWS * np.log(2.0), rel=1e-6)
-    res = s.lbfgs_solve(x, rho=0.01, max_iter=3)
+    res = s.lbfgs_solve(x, rho=0.01, max_iter=3, linesearch=linesearch)
     assert res["evals"] >= 2 and res["f"] < f_start * 0.99
     assert s.logistic_fg(x, g, rho=0.01) == pytest.approx(res["f"], rel=1e-7)
+    # second solve from the same x with a consensus point and a dual that have moved
+    z = ctx.vec(DIM, np.full(DIM, 1e-3, np.float32))
+    f2_start = s.logistic_fg(x, g, z=z, rho=0.01)
+    res2 = s.lbfgs_solve(x, z=z, rho=0.01, max_iter=3, linesearch=linesearch)
+    assert res2["f"] < f2_start
+    assert s.logistic_fg(x, g, z=z, rho=0.01) == pytest.approx(res2["f"], rel=1e-7)
+    # its first evaluation cost no sweep: forward sweeps = one X d per iteration (+ full evaluations)
+    if linesearch == 1:
+        assert res2["forward_sweeps"] == res2["evals"] - 1
+    else:
+        assert res2["transposed_sweeps"] == res2["iters"]
+
+
+def test_lbfgs_modes_agree(big):
+    """inside one solve the three modes walk the same points (to float rounding)"""
+    ctx, s = big
+    out = []
+    for mode in (1, 0, 2):
+        x = ctx.vec(DIM)
+        res = s.lbfgs_solve(x, rho=0.01, max_iter=4, linesearch=mode)
+        out.append((res, x.download()))
+    (r1, x1), (r0, x0), (r2, x2) = out
+    assert r0["evals"] == r1["evals"] == r2["evals"] and r0["iters"] == r1["iters"] == r2["iters"]
+    assert r0["f"] == pytest.approx(r1["f"], rel=1e-7) and r2["f"] == pytest.approx(r1["f"], rel=1e-6)
+    scale = np.abs(x1).max()
+    assert np.abs(x0 - x1).max() <= 1e-5 * scale and np.abs(x2 - x1).max() <= 1e-4 * scale
 
 
 def test_consensus_fixed_point(big):
