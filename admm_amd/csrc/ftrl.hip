@@ -32,6 +32,15 @@ __device__ inline float seq_weight(float z, float n, float c, float alpha, float
   return (float)((double)num / den);
 }
 
+// the same with sqrt(n) (in double) supplied by the caller, who needs it again for the update
+__device__ inline float seq_weight_sn(float z, double sqrt_n, float c, float alpha, float beta, float l1, float l2) {
+  const float sign = z < 0.0f ? -1.0f : 1.0f;
+  const float num = sign * 1 - z + l2 * c;
+  const double den = ((double)beta + sqrt_n) / (double)alpha + (double)l2;
+  const float w = (float)((double)num / den);
+  return sign * z <= l1 ? 0.0f : w;
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -276,6 +285,7 @@ __device__ __forceinline__ void ftrl_ring_body(const SeqArgs &a, const uint32_t 
       const uint32_t len = s_len[u];
       float sw = 0.0f, so = 0.0f;
       float zj[EPL], nj[EPL], wj[EPL];
+      double sn[EPL];  // sqrt(n) of the coordinate before this row's update: used by the weight and by sigma
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
@@ -287,7 +297,8 @@ __device__ __forceinline__ void ftrl_ring_body(const SeqArgs &a, const uint32_t 
         const float rz = ring_z[slot][fwd ? pos : 0], rn = ring_n[slot][fwd ? pos : 0];
         zj[e] = fwd ? rz : g_z[u % kAhead][e];
         nj[e] = fwd ? rn : g_n[u % kAhead][e];
-        wj[e] = seq_weight(zj[e], nj[e], g_r[u % kAhead][e], a.alpha, a.beta, a.l1, a.l2);
+        sn[e] = sqrt((double)nj[e]);
+        wj[e] = seq_weight_sn(zj[e], sn[e], g_r[u % kAhead][e], a.alpha, a.beta, a.l1, a.l2);
         if (k < len) w[s_col[u][e]] = wj[e];
         sw += k < len ? wj[e] * s_val[u][e] : 0.0f;
         so += k < len ? g_o[u % kAhead][e] * s_val[u][e] : 0.0f;
@@ -299,7 +310,7 @@ __device__ __forceinline__ void ftrl_ring_body(const SeqArgs &a, const uint32_t 
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const uint32_t k = lane + 64 * e;
-        const double sigma = (sqrt((double)(nj[e] + g2)) - sqrt((double)nj[e])) / (double)a.alpha;
+        const double sigma = (sqrt((double)(nj[e] + g2)) - sn[e]) / (double)a.alpha;
         const float zn = (float)((double)zj[e] + ((double)g - sigma * (double)wj[e]));
         const float nn = nj[e] + g2;
         if (k < len && !tail) {
