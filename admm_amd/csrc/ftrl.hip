@@ -337,9 +337,15 @@ __device__ __forceinline__ void ftrl_ring_body(const SeqArgs &a, const uint32_t 
       }
       {
         const long long tn = t + kStatic;
-        const unsigned long long b = __shfl(nx_lo, u, 64);
-        const unsigned long long e1 = __shfl(nx_hi, u, 64);
-        s_lab[u] = __shfl(nx_lab, u, 64);
+        // lane u of the group's registers, read with v_readlane (scalar results, no LDS trip)
+        auto lane64 = [](unsigned long long v, int src) {
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+          return ((unsigned long long)hi << 32) | lo;
+        };
+        const unsigned long long b = lane64(nx_lo, u);
+        const unsigned long long e1 = lane64(nx_hi, u);
+        s_lab[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nx_lab), u));
         s_len[u] = tn < total ? (uint32_t)(e1 - b) : 0u;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
