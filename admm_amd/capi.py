@@ -20,7 +20,7 @@ SYMBOLS = [
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
     "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_destroy",
-    "admm_predict", "admm_metrics", "admm_ftrl_pass", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
+    "admm_predict", "admm_metrics", "admm_auc_scores", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus",
     "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32",
 ]
@@ -90,6 +90,8 @@ def load():
         "admm_predict": [vp, C.POINTER(vp), i32, vp],
         "admm_metrics": [vp, C.POINTER(vp), i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                          C.POINTER(u64)],
+        "admm_auc_scores": [vp, vp, vp, u64, C.POINTER(C.c_double)],
+        "admm_csr_copy_labels": [vp, vp],
         "admm_ftrl_pass": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, u64],
         "admm_ftrl_pass_multi": [vp, vp, vp, vp, vp, vp, C.c_int, f32, f32, f32, f32],
         "admm_logistic_fg": [vp, vp, vp, vp, vp, f32, C.POINTER(C.c_double), vp],
@@ -243,6 +245,12 @@ class Context:
     def dual_update(self, ydual, x, z, rho):
         _check(self.L.admm_dual_update(self.h, ydual.ptr, x.ptr, z.ptr, rho, x.n))
 
+    def auc_scores(self, scores, labels, n):
+        """tie-aware rank-sum AUC (src/metrics.cc:14-89) of n (score, label) pairs held in device vectors"""
+        auc = C.c_double()
+        _check(self.L.admm_auc_scores(self.h, scores.ptr, labels.ptr, int(n), C.byref(auc)))
+        return auc.value
+
     def consensus(self, total, num_worker, rho, global_var, l1, x, ydual, z, want_residuals=True):
         r2, s2 = C.c_double(), C.c_double()
         _check(self.L.admm_consensus(self.h, total.ptr, num_worker, rho, global_var, l1, x.ptr,
@@ -294,6 +302,14 @@ class SampleSet:
     def _groups(self, groups):
         arr = (C.c_void_p * len(groups))(*[g.ptr.value for g in groups])
         return C.cast(arr, C.POINTER(C.c_void_p)), len(groups)
+
+    def predict_into(self, groups, out):
+        """per-row P(y=1|x) into a device vector of at least nrows floats"""
+        arr, k = self._groups(groups)
+        _check(self.ctx.L.admm_predict(self.h, arr, k, out.ptr))
+
+    def copy_labels(self, out):
+        _check(self.ctx.L.admm_csr_copy_labels(self.h, out.ptr))
 
     def predict(self, groups):
         out = DeviceVec(self.ctx, max(self.nrows, 1))

@@ -58,9 +58,7 @@ __global__ void __launch_bounds__(256) k_auc_sum(const uint32_t *__restrict__ st
   if (threadIdx.x == 0) partials[1 * kMaxPartialBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-int auc_device(admm_csr *csr, const float *scores, double *auc_out) {
-  admm_ctx *ctx = csr->ctx;
-  const uint64_t n = csr->nrows;
+int auc_scores(admm_ctx *ctx, const float *labels, const float *scores, uint64_t n, double *auc_out) {
   ADMM_REQUIRE(n < 0x7FFFFFFFull, "admm_metrics: AUC supports up to 2^31-1 rows");
   float *keys = nullptr;
   uint32_t *flag_in = nullptr, *flag_out = nullptr, *start = nullptr;
@@ -83,7 +81,7 @@ int auc_device(admm_csr *csr, const float *scores, double *auc_out) {
   AUC_CHECK(hipMalloc(&flag_out, sizeof(uint32_t) * n));
   AUC_CHECK(hipMalloc(&start, sizeof(uint32_t) * n));
   const int grid = grid_for(n, 256, ctx->cu_count * 8);
-  hipLaunchKernelGGL(k_auc_flags, dim3(grid), dim3(256), 0, ctx->stream, csr->d_label, flag_in, n);
+  hipLaunchKernelGGL(k_auc_flags, dim3(grid), dim3(256), 0, ctx->stream, labels, flag_in, n);
   size_t bytes = 0, bytes2 = 0;
   AUC_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, scores, keys, flag_in, flag_out, (size_t)n, 0, 32, ctx->stream));
   AUC_CHECK(rocprim::inclusive_scan(nullptr, bytes2, start, start, (size_t)n, rocprim::maximum<uint32_t>(), ctx->stream));
@@ -104,4 +102,22 @@ int auc_device(admm_csr *csr, const float *scores, double *auc_out) {
   return ADMM_OK;
 }
 
+int auc_device(admm_csr *csr, const float *scores, double *auc_out) {
+  return auc_scores(csr->ctx, csr->d_label, scores, csr->nrows, auc_out);
+}
+
 }  // namespace admm_impl
+
+extern "C" int admm_auc_scores(admm_ctx *ctx, const float *scores, const float *labels, uint64_t n, double *auc) {
+  ADMM_REQUIRE(ctx && auc && (n == 0 || (scores && labels)), "admm_auc_scores: NULL argument");
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  return admm_impl::auc_scores(ctx, labels, scores, n, auc);
+}
+
+extern "C" int admm_csr_copy_labels(admm_csr *csr, float *dst) {
+  ADMM_REQUIRE(csr && (dst || csr->nrows == 0), "admm_csr_copy_labels: NULL argument");
+  if (csr->nrows == 0) return ADMM_OK;
+  ADMM_HIP_CHECK(hipSetDevice(csr->ctx->device));
+  ADMM_HIP_CHECK(hipMemcpyAsync(dst, csr->d_label, sizeof(float) * csr->nrows, hipMemcpyDeviceToDevice, csr->ctx->stream));
+  return ADMM_OK;
+}

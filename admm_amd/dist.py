@@ -40,6 +40,27 @@ def allreduce_sum_(t):
     return t
 
 
+def gather_slices_(buf, offset, count):
+    """All ranks' slices of `buf` together on every rank: each rank has filled buf[offset:offset+count]
+    (its own rows) and left the rest zero, so a sum over ranks is the concatenation.  Works with any
+    backend that has a sum all-reduce (the same exchange serves the C++ programs through
+    admm_allreduce_sum_f32).  Returns buf."""
+    assert 0 <= offset and offset + count <= buf.numel()
+    return allreduce_sum_(buf)
+
+
+def slice_of_rank(count):
+    """(offset, total) of this rank's `count` rows in the concatenation over ranks, rank order."""
+    rank, world, _ = env_rank_world()
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return 0, int(count)
+    counts = torch.zeros(world, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    counts[rank] = int(count)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    counts = counts.tolist()
+    return int(sum(counts[:rank])), int(sum(counts))
+
+
 def allreduce_max_(t):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

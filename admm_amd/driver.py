@@ -242,6 +242,30 @@ def admm_iteration(worker, master, train_parts, test_set, admm_params, global_we
     return dict(line=line, r2=r2, s2=s2, stats=stats)
 
 
+def global_test_metrics(ctx, test_set, groups):
+    """Logloss and AUC over the test rows of ALL ranks (the reference reports them per rank only,
+    src/admm_allreduce.cpp:76-81): every rank predicts into its slice of a zero-filled buffer and
+    copies its labels into a second one, a sum all-reduce concatenates them, and every rank then
+    runs the device AUC (src/metrics.cc:14-89) once over the whole.  Returns (logloss, auc, rows)."""
+    import torch
+    from . import capi, dist as adist
+    n = test_set.nrows
+    off, total = adist.slice_of_rank(n)
+    buf = torch.zeros(2 * max(total, 1), dtype=torch.float32, device="cuda")
+    base = buf.data_ptr()
+    if n:
+        test_set.predict_into(groups, capi.DeviceVec.from_ptr(ctx, base + 4 * off, n))
+        test_set.copy_labels(capi.DeviceVec.from_ptr(ctx, base + 4 * (max(total, 1) + off), n))
+    ctx.sync()
+    adist.gather_slices_(buf, off, n)
+    torch.cuda.synchronize()
+    loss_local, _, _ = test_set.metrics(groups, want_auc=False) if n else (0.0, None, 0)
+    sums = adist.allreduce_sum_(torch.tensor([loss_local * n, float(n)], dtype=torch.float64, device="cuda"))
+    auc = ctx.auc_scores(capi.DeviceVec.from_ptr(ctx, base, total),
+                         capi.DeviceVec.from_ptr(ctx, base + 4 * max(total, 1), total), total)
+    return float(sums[0] / sums[1]), auc, total
+
+
 def format_line(psid, loss, auc, n):
     """the per-iteration report of src/admm_allreduce.cpp:79"""
     return "%s | %.7f | %.7f | %d" % (psid, loss, auc, n)

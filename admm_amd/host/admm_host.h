@@ -109,6 +109,7 @@ class AdmmConfig {
   real_t global_l1 = 0;                // soft threshold of the consensus update
   std::string local_solver = "ftrl";   // ftrl | lbfgs
   uint64_t ftrl_batch = 1;             // 1 = the reference's row-by-row FTRL
+  int global_metrics = 0;              // 1: rank 0 also reports logloss / AUC over all ranks' test rows
   admm_lbfgs_params lbfgs = {6, 10, 20, 1e-5f, 1e-4f, 0.9f, 0};
 };
 
@@ -256,6 +257,11 @@ class Metrics {
   // both in one sweep
   void Both(::admm::SampleSet &sample_set, std::vector<const ::admm::DeviceVector *> &weights, real_t *loss,
             real_t *auc);
+  // Logloss and AUC over the test rows of all ranks (the reference reports them per rank only):
+  // every rank predicts into its slice of a zero-filled buffer, a sum all-reduce concatenates the
+  // slices, and the device AUC runs once over the whole.  Collective: every rank must call it.
+  void AllRanks(::admm::Runtime &rt, ::admm::SampleSet &sample_set, std::vector<const ::admm::DeviceVector *> &weights,
+                double *loss, double *auc, uint64_t *rows);
 };
 
 // src/admm.h: text (de)serialisation of the worker and global state

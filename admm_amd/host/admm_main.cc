@@ -65,6 +65,13 @@ int main(int argc, char *argv[]) {
         metrics.Both(test_set, group_w, &loss, &auc);
         rt.TrackerPrintf("%s | %.7f | %.7f | %d\n", worker.psid_.c_str(), loss, auc, test_set.Size());
       }
+      if (prm.global_metrics) {  // conf key of this build: the same two numbers over all ranks' test rows
+        std::vector<const ::admm::DeviceVector *> group_w = {&worker.base_vec_, &worker.bias_vec_};
+        double gl = 0, ga = 0;
+        uint64_t gn = 0;
+        metrics.AllRanks(rt, test_set, group_w, &gl, &ga, &gn);
+        if (rt.GetRank() == 0) rt.TrackerPrintf("all | %.7f | %.7f | %llu\n", gl, ga, (unsigned long long)gn);
+      }
 
       double r2 = 0, s2 = 0;  // GlobalUpdate + LangrangeUpdate, fused
       ADMM_CHECK(master_processor.Consensus(tmp, prm, rt.GetWorldSize(), worker, &r2, &s2));

@@ -53,6 +53,7 @@ void ArgParser::ADMMParse(const char *file, AdmmConfig &p) {
   if (d.count("test_path")) p.test_path = d["test_path"];
   if (d.count("output_path")) p.output_path = d["output_path"];
   if (d.count("global_l1")) p.global_l1 = (float)std::atof(d["global_l1"].c_str());
+  if (d.count("global_metrics")) p.global_metrics = std::atoi(d["global_metrics"].c_str());
   if (d.count("local_solver")) p.local_solver = d["local_solver"];
   if (d.count("ftrl_batch")) p.ftrl_batch = std::max(1, std::atoi(d["ftrl_batch"].c_str()));
   if (d.count("lbfgs_m")) p.lbfgs.m = std::atoi(d["lbfgs_m"].c_str());

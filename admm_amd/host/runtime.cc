@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -95,8 +96,9 @@ void Runtime::AllreduceSum(float *device_buf, size_t n) {
 // ---- all-reduce through host shared memory ------------------------------------------------------
 //
 // Segment layout: a header of two counters (arrivals, generation), then one slot of n floats per
-// rank.  Rank 0 creates the file at the first call (the length n is known then); the others wait
-// for it to reach its full size.
+// rank.  Rank 0 creates the file at the first call (slots sized for that call's length, at least
+// 64 Ki floats); the others wait for it to reach its full size.  A longer vector goes through in
+// slot-sized pieces.
 
 namespace {
 struct ShmHeader {
@@ -123,8 +125,8 @@ void Runtime::ShmBarrier() {
 
 void Runtime::ShmAllreduce(float *device_buf, size_t n) {
   if (!shm_) {
-    shm_n_ = n;
-    shm_bytes_ = sizeof(ShmHeader) + sizeof(float) * n * (size_t)world_;
+    shm_n_ = std::max<size_t>(n, 65536);
+    shm_bytes_ = sizeof(ShmHeader) + sizeof(float) * shm_n_ * (size_t)world_;
     int fd = -1;
     if (rank_ == 0) {
       const std::string tmp = shm_path_ + ".tmp";
@@ -146,17 +148,19 @@ void Runtime::ShmAllreduce(float *device_buf, size_t n) {
     close(fd);
     ADMM_CHECK(shm_ != MAP_FAILED);
   }
-  ADMM_CHECK(n == shm_n_);  // the reference reduces one length only (dim)
   float *slots = reinterpret_cast<float *>(static_cast<char *>(shm_) + sizeof(ShmHeader));
-  ADMM_CALL(admm_vec_download(ctx_, slots + (size_t)rank_ * n, device_buf, n));
-  ShmBarrier();
-  std::vector<float> sum(slots, slots + n);  // rank 0's slot, then the others in rank order
-  for (int r = 1; r < world_; ++r) {
-    const float *s = slots + (size_t)r * n;
-    for (size_t i = 0; i < n; ++i) sum[i] += s[i];
+  for (size_t done = 0; done < n; done += shm_n_) {
+    const size_t m = std::min(shm_n_, n - done);
+    ADMM_CALL(admm_vec_download(ctx_, slots + (size_t)rank_ * shm_n_, device_buf + done, m));
+    ShmBarrier();
+    std::vector<float> sum(slots, slots + m);  // rank 0's slot, then the others in rank order
+    for (int r = 1; r < world_; ++r) {
+      const float *s = slots + (size_t)r * shm_n_;
+      for (size_t i = 0; i < m; ++i) sum[i] += s[i];
+    }
+    ShmBarrier();  // nobody refills its slot before every rank has read all of them
+    ADMM_CALL(admm_vec_upload(ctx_, device_buf + done, sum.data(), m));
   }
-  ShmBarrier();  // nobody refills its slot before every rank has read all of them
-  ADMM_CALL(admm_vec_upload(ctx_, device_buf, sum.data(), n));
 }
 
 DeviceVector &DeviceVector::operator=(const DeviceVector &o) {

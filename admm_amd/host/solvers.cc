@@ -130,6 +130,50 @@ void Metrics::Both(::admm::SampleSet &sample_set, std::vector<const DeviceVector
   if (auc) *auc = (real_t)a;
 }
 
+void Metrics::AllRanks(::admm::Runtime &rt, ::admm::SampleSet &sample_set, std::vector<const DeviceVector *> &weights,
+                       double *loss, double *auc, uint64_t *rows) {
+  ADMM_CHECK(!weights.empty() && weights.size() <= 4);
+  const int world = rt.GetWorldSize(), rank = rt.GetRank();
+  const uint64_t n = sample_set.device() ? (uint64_t)sample_set.Size() : 0;
+  // row counts and loss sums of all ranks; floats carry them exactly in two halves each
+  double lsum = 0;
+  const float *groups[4];
+  for (size_t i = 0; i < weights.size(); ++i) groups[i] = weights[i]->data();
+  if (n) {
+    double l = 0;
+    ADMM_CALL(admm_metrics(sample_set.device(), groups, (int)weights.size(), &l, nullptr, nullptr));
+    lsum = l * (double)n;
+  }
+  std::vector<float> meta((size_t)world * 4, 0.0f);
+  meta[rank * 4 + 0] = (float)(n >> 20);
+  meta[rank * 4 + 1] = (float)(n & 0xFFFFFu);
+  meta[rank * 4 + 2] = (float)lsum;
+  meta[rank * 4 + 3] = (float)(lsum - (double)meta[rank * 4 + 2]);
+  DeviceVector dmeta(meta.size());
+  dmeta.from_host(meta);
+  rt.AllreduceSum(dmeta.data(), meta.size());
+  meta = dmeta.to_host();
+  uint64_t total = 0, off = 0;
+  double ltotal = 0;
+  for (int r = 0; r < world; ++r) {
+    const uint64_t c = ((uint64_t)meta[r * 4 + 0] << 20) + (uint64_t)meta[r * 4 + 1];
+    if (r < rank) off += c;
+    total += c;
+    ltotal += (double)meta[r * 4 + 2] + (double)meta[r * 4 + 3];
+  }
+  DeviceVector buf(2 * std::max<uint64_t>(total, 1));  // zero-filled: [scores | labels]
+  if (n) {
+    ADMM_CALL(admm_predict(sample_set.device(), groups, (int)weights.size(), buf.data() + off));
+    ADMM_CALL(admm_csr_copy_labels(sample_set.device(), buf.data() + std::max<uint64_t>(total, 1) + off));
+  }
+  rt.AllreduceSum(buf.data(), buf.size());
+  double a = 0;
+  ADMM_CALL(admm_auc_scores(rt.ctx(), buf.data(), buf.data() + std::max<uint64_t>(total, 1), total, &a));
+  if (loss) *loss = total ? ltotal / (double)total : 0.0;
+  if (auc) *auc = a;
+  if (rows) *rows = total;
+}
+
 Metrics::real_t Metrics::Auc(::admm::SampleSet &sample_set, std::vector<const DeviceVector *> &weights, bool) {
   real_t a = 0;
   Both(sample_set, weights, nullptr, &a);

@@ -193,6 +193,9 @@ def main():
                           "nnz_per_s": float(o.item()) / o_dt, "steps": 2})
         prm.lbfgs["linesearch"] = args.linesearch
 
+    # test logloss / AUC over the test rows of all ranks together, once, after the timed work
+    g_loss, g_auc, g_rows = driver.global_test_metrics(ctx, test, [worker.base_vec_, worker.bias_vec_])
+
     # max time and total swept entries over ranks
     # entries swept: every sweep of the sample set counts its stored entries once, so a forward +
     # transposed pair (one objective/gradient evaluation) counts them twice over two: nnz per pair
@@ -259,6 +262,7 @@ def main():
                 "forward_sweeps_total": fwd_total, "transposed_sweeps_total": tr_total,
                 "admm_iterations_per_s": args.steps / dt,
                 "other_line_search": other,
+                "global_test_metrics": {"logloss": g_loss, "auc": g_auc, "rows": g_rows},
                 "generate_and_build_s": t_gen,
                 "rank0_hbm_bytes": dict(zip(("row_major", "column_block_copy"), train.bytes())),
                 "last_line": driver.format_line("rank0", *last_rec["line"]) if last_rec and last_rec["line"] else None,

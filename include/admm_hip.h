@@ -131,6 +131,16 @@ int admm_predict(admm_csr *csr, const float *const *groups, int ngroups, float *
  * on the device in double.  Either output pointer may be NULL. */
 int admm_metrics(admm_csr *csr, const float *const *groups, int ngroups, double *logloss_mean,
                  double *auc, uint64_t *nrows);
+/* Metrics::Auc + Metrics::Sort (src/metrics.cc:14-89) on bare arrays: the same tie-aware rank-sum
+ * AUC over n (score, label) pairs in DEVICE memory.  The reference reports one AUC per rank; a
+ * job that wants the AUC of all ranks' test rows together gathers the ranks' scores and labels
+ * (admm_predict into one rank's slice of a zero-filled buffer + a sum all-reduce does it) and
+ * calls this once. */
+int admm_auc_scores(admm_ctx *ctx, const float *scores, const float *labels, uint64_t n,
+                    double *auc);
+/* Copies the nrows labels of the sample set (as stored: the file's labels, src/sample_set.cc:41)
+ * to dst, a DEVICE buffer. */
+int admm_csr_copy_labels(admm_csr *csr, float *dst);
 
 /* ---- FTRL-proximal (FtrlSolver, src/ftrl.cc:36-145) --------------------------------------- */
 

@@ -36,6 +36,13 @@ for it in range(conf.passes):
     zg = orc.global_update(total, world, conf.step_size, conf.global_var)
     orc.dual_update(wk.y, wk.x, zg, conf.step_size)
     hist.append((total.copy(), zg.copy(), wk.x.copy(), wk.y.copy()))
+# the exchange behind the all-ranks test metrics: every rank fills its slice of a zero buffer
+mine = np.arange(3 + 2 * rank, dtype=np.float32) + 100 * (rank + 1)
+off, tot = adist.slice_of_rank(mine.size)
+buf = torch.zeros(tot, dtype=torch.float32)
+buf[off:off + mine.size] = torch.from_numpy(mine)
+adist.gather_slices_(buf, off, mine.size)
+hist.append((off, tot, buf.numpy().copy()))
 adist.barrier()
 with open(os.environ["ADMM_OUT"] + ".%d" % rank, "wb") as f:
     pickle.dump(hist, f)
@@ -66,6 +73,12 @@ def test_two_ranks_gloo(tmp_path, oracle):
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0, out
     hists = [pickle.load(open(str(tmp_path / "hist") + ".%d" % r, "rb")) for r in range(2)]
+    # slices gathered over ranks: rank order, every rank sees the whole
+    want = np.concatenate([np.arange(3, dtype=np.float32) + 100, np.arange(5, dtype=np.float32) + 200])
+    for r in range(2):
+        off, tot, got = hists[r].pop()
+        assert (off, tot) == ((0, 8) if r == 0 else (3, 8))
+        np.testing.assert_array_equal(got, want)
     # single-process run of the same two ranks
     dim, total_rows = 97, 1001
     parts = []

@@ -119,6 +119,28 @@ def test_auc_with_ties_and_zero_weights(ctx, oracle):
     dev.destroy()
 
 
+def test_auc_on_arrays_and_all_ranks_metrics(ctx, oracle):
+    """admm_auc_scores on bare (score, label) arrays with ties, and the all-ranks test metrics of
+    the driver, which for one rank must be the sample set's own metrics"""
+    from admm_amd import driver
+    rng = np.random.default_rng(21)
+    n = 5000
+    scores = np.round(rng.random(n), 2).astype(np.float32)          # many ties
+    labels = rng.integers(0, 2, n).astype(np.float32)
+    got = ctx.auc_scores(ctx.vec(n, scores), ctx.vec(n, labels), n)
+    close(got, oracle.auc_from_scores(scores, labels, f64=True))
+    dim = 2000
+    raw = make_synth_csr(3000, dim, 12, seed=17)
+    dev = upload(ctx, raw, dim)
+    w = ctx.vec(dim, rng.normal(0, 0.3, dim).astype(np.float32))
+    b = ctx.vec(dim, rng.normal(0, 0.05, dim).astype(np.float32))
+    ll, auc, rows = dev.metrics([w, b])
+    g_ll, g_auc, g_rows = driver.global_test_metrics(ctx, dev, [w, b])
+    assert g_rows == rows and g_auc == auc
+    close(g_ll, ll, rtol=1e-12)
+    dev.destroy()
+
+
 # ------------------------------------------------------------------------------------------------
 # FTRL
 # ------------------------------------------------------------------------------------------------

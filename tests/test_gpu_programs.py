@@ -167,7 +167,7 @@ def test_three_workers_under_the_local_launcher(tmp_path, oracle):
     os.makedirs(tmp_path / "out")
     conf = tmp_path / "admm.conf"
     conf.write_text("step_size = 0.01\nbias_var = 0.01\nglobal_var = 4\nftrl_alpha = 0.1\npasses = 3\n"
-                    "dim = %d\nA : 1\nB : 1\nC : 1\n" % dim)
+                    "global_metrics = 1\ndim = %d\nA : 1\nB : 1\nC : 1\n" % dim)
     out = _run([os.path.join(ROOT, "tools", "dmlc_local.py"), "-n", "3", "--allreduce", "shm",
                 os.path.join(BIN, "admm"), str(conf), str(tmp_path / "train"), str(tmp_path / "test"),
                 str(tmp_path / "out")])
@@ -189,6 +189,18 @@ def test_three_workers_under_the_local_launcher(tmp_path, oracle):
         x = _read_sparse_sections(tmp_path / "out" / ("admm_weight_" + name))[0]
         np.testing.assert_allclose(x, workers[k].x, rtol=2e-5, atol=1e-6 * max(1.0, np.abs(workers[k].x).max()))
     assert [int(x) for x in re.findall(r"^Finish (\d+)-th iteration$", out, flags=re.M)] == [0, 1, 2]
+    # global_metrics = 1: rank 0 also reports logloss and AUC over the test rows of all three ranks
+    alls = re.findall(r"^all \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out, flags=re.M)
+    assert len(alls) == 3 and all(int(n) == 600 for _, _, n in alls)
+    for (l, _, _), r in zip(alls, rec):      # equal test sizes: the mean of the per-rank loglosses
+        assert float(l) == pytest.approx(np.mean([r["lines"][k][0] for k in range(3)]), rel=2e-5)
+    scores, labels = [], []
+    for k in range(3):                       # last iteration: the saved x is the one that was scored
+        _, p = oracle.logloss_sum_f64(tests[k], [workers[k].x, workers[k].bias], want_p=True)
+        scores.append(p)
+        labels.append(tests[k].label)
+    want = oracle.auc_from_scores(np.concatenate(scores), np.concatenate(labels), f64=True)
+    assert float(alls[-1][1]) == pytest.approx(want, rel=5e-5)
 
 
 def test_launcher_restarts_on_254_and_reports_failures(tmp_path):
