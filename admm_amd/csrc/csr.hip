@@ -424,7 +424,9 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
                                uint64_t dim, int add_bias, admm_csr **out) {
   ADMM_REQUIRE(ctx && rowptr && label && out, "admm_csr_upload: NULL argument");
   ADMM_REQUIRE(nnz == 0 || col, "admm_csr_upload: col is NULL");
-  ADMM_REQUIRE(dim > 0 && dim <= 0xFFFFFFFFull, "admm_csr_upload: dim %llu out of range",
+  // 2^30: the forward sweep addresses the gathered vector through a buffer resource whose size
+  // field is 32 bits of bytes
+  ADMM_REQUIRE(dim > 0 && dim < (1ull << 30), "admm_csr_upload: dim %llu out of range (below 2^30)",
                (unsigned long long)dim);
   ADMM_REQUIRE(nrows < 0xFFFFFFFFull, "admm_csr_upload: at most 2^32-1 rows per sample set");
   ADMM_REQUIRE(rowptr[0] == 0 && rowptr[nrows] == nnz, "admm_csr_upload: rowptr does not span nnz");
@@ -648,6 +650,12 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
     csr->hot_dense = true;
   }
   csr->cache_valid = false;
+  // tables a sequential FTRL pass built before the relabelling hold (or lack) column ids in the old
+  // numbering: drop them, the next pass rebuilds both
+  for (void **p : {(void **)&csr->d_dep, (void **)&csr->d_seqcol}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
 #undef RL_CHECK
   // a transposed copy built earlier still holds the entries the mask now covers: rebuild it
   if (csr->has_t && csr->hot_dense) return admm_csr_build_transposed(csr, csr->panel_rows, csr->col_block);
@@ -775,7 +783,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
 
 extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_csr **out) {
   ADMM_REQUIRE(ctx && spec && out, "admm_csr_synth: NULL argument");
-  ADMM_REQUIRE(spec->dim >= 3 && spec->dim <= 0xFFFFFFFFull, "admm_csr_synth: dim out of range");
+  ADMM_REQUIRE(spec->dim >= 3 && spec->dim < (1ull << 30), "admm_csr_synth: dim out of range (3 .. 2^30 - 1)");
   ADMM_REQUIRE(spec->max_len >= 1 && spec->max_len <= 1024, "admm_csr_synth: max_len must be in [1, 1024]");
   ADMM_REQUIRE(spec->zipf_s > 1.0f, "admm_csr_synth: zipf_s must be > 1");
   ADMM_REQUIRE(spec->nrows < 0xFFFFFFFFull, "admm_csr_synth: at most 2^32-1 rows per sample set");

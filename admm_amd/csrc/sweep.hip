@@ -60,7 +60,7 @@ constexpr int kFwRowSlots = 128;
 constexpr int kFwChunk = 8192;
 constexpr int kFwHot = 16384;
 constexpr int kFwSlots = 4;                                  // tiles whose row data is resident in LDS
-constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 2) * kFwRowSlots) +
+constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 4) * kFwRowSlots) +
                           sizeof(unsigned long long) * (kFwSlots * (kFwRowSlots + 2) + kFwSlots * kFwRowSlots +
                                                         2 * kFwRowSlots * kWarmWords + 2 * 64 * kWarmWords + kWarmWords) + 64;
 
@@ -104,8 +104,10 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   float *hot = prod0 + 2 * kFwChunk;                                    // [kFwHot]
   float *tab = hot + kFwHot;                                            // [8][256] byte -> sum of hot weights
   float *lab0 = tab + 8 * 256;                                          // [kFwSlots][kFwRowSlots] labels
-  float *out_s = lab0 + kFwSlots * kFwRowSlots;                         // [kFwRowSlots] per-row results of the tile
-  float *out2_s = out_s + kFwRowSlots;                                  // [kFwRowSlots] row sums of the tile (FWD_LBFGS)
+  // per-row results of a tile, two halves: the consumers fill half (i & 1) for tile i while the
+  // producers copy tile i-1's results out of the other half
+  float *out_s0 = lab0 + kFwSlots * kFwRowSlots;                        // [2][kFwRowSlots] per-row results of a tile
+  float *out2_s0 = out_s0 + 2 * kFwRowSlots;                            // [2][kFwRowSlots] row sums of a tile (FWD_LBFGS)
   __shared__ double shred[16];
   // after the tile loop the product buffer is free: per-wave column sums are combined there
   unsigned long long(*hsum)[64] = reinterpret_cast<unsigned long long(*)[64]>(prod0);
@@ -274,9 +276,10 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
     // consumer wave would queue behind everything the producers have in the memory pipe)
     if (i > 0) {
       const uint64_t ptile = tile_of(i - 1);
+      const int ph = (int)((i - 1) & 1) * kFwRowSlots;
       if (ptid < tile_rows(ptile)) {
-        a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
-        if (MODE == FWD_LBFGS && a.out2) a.out2[a.r0 + ptile * rpt + ptid] = out2_s[ptid];
+        a.out[a.r0 + ptile * rpt + ptid] = out_s0[ph + ptid];
+        if (MODE == FWD_LBFGS && a.out2) a.out2[a.r0 + ptile * rpt + ptid] = out2_s0[ph + ptid];
       }
     }
     // row data of the tile three ahead, parked in LDS at the end of the step: producer threads
@@ -417,6 +420,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
       // of their own.
       unsigned long long my_r = 0, my_r2 = 0;
       const unsigned long long my_m = (dense && trow < nr) ? mask_s[trow] : 0ull;
+      float *out_s = out_s0 + (int)(i & 1) * kFwRowSlots, *out2_s = out2_s0 + (int)(i & 1) * kFwRowSlots;
       if (q == 0 && trow < nr) {
         const float m = rowsum;
         const float lab = lab0[slot * kFwRowSlots + trow];
@@ -492,9 +496,10 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
 #undef FW_TILE_HEAD
   if (producer && nmine > 0) {
     const uint64_t ptile = tile_of(nmine - 1);
+    const int ph = (int)((nmine - 1) & 1) * kFwRowSlots;
     if (ptid < tile_rows(ptile)) {
-      a.out[a.r0 + ptile * rpt + ptid] = out_s[ptid];
-      if (MODE == FWD_LBFGS && a.out2) a.out2[a.r0 + ptile * rpt + ptid] = out2_s[ptid];
+      a.out[a.r0 + ptile * rpt + ptid] = out_s0[ph + ptid];
+      if (MODE == FWD_LBFGS && a.out2) a.out2[a.r0 + ptile * rpt + ptid] = out2_s0[ph + ptid];
     }
   }
   if (colsums) {
@@ -610,8 +615,8 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   a.mode = (int)mode;
   a.nhot = (uint32_t)std::min<uint64_t>(kFwHot, csr->dim);
   a.dim = (uint32_t)csr->dim;
-  static bool raised = false;
-  if (!raised) {
+  static bool raised[64] = {};  // per device: function attributes belong to a device's copy of the code
+  if (!raised[ctx->device & 63]) {
     for (const void *fn : {reinterpret_cast<const void *>(&k_forward<FWD_EVAL, true>),
                            reinterpret_cast<const void *>(&k_forward<FWD_LBFGS, true>),
                            reinterpret_cast<const void *>(&k_forward<FWD_FTRL, true>),
@@ -621,7 +626,7 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
                            reinterpret_cast<const void *>(&k_forward<FWD_MARGIN, true>),
                            reinterpret_cast<const void *>(&k_forward<FWD_MARGIN, false>)})
       ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds));
-    raised = true;
+    raised[ctx->device & 63] = true;
   }
   // rows per tile: as many as normally fit one chunk of stored entries, with some headroom
   {
@@ -817,12 +822,15 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
                                : sizeof(fx_t) * csr->col_block;
   // more than half of the CU's LDS: one workgroup per CU, so give it the full 1024 threads
   const bool big = lds > 72 * 1024;
-  static bool raised = false;
-  if (!raised) {
+  static bool raised[64] = {};  // per device
+  if (!raised[ctx->device & 63]) {
+    // the 512-thread forms run with up to 72 KB, which is above the 64 KB a kernel gets by default
     for (const void *fn : {reinterpret_cast<const void *>(&k_transposed<true, 1024>),
-                           reinterpret_cast<const void *>(&k_transposed<false, 1024>)})
+                           reinterpret_cast<const void *>(&k_transposed<false, 1024>),
+                           reinterpret_cast<const void *>(&k_transposed<true, 512>),
+                           reinterpret_cast<const void *>(&k_transposed<false, 512>)})
       ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    raised = true;
+    raised[ctx->device & 63] = true;
   }
   KernelTimer t(ctx, ADMM_K_TRANSPOSED);
   // keep each launch's grid below 2^30 workgroups
@@ -1262,7 +1270,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   const bool from_margins = P.linesearch != 1;
   const bool cheap_accept = P.linesearch == 2;
   const uint64_t dim = csr->dim;
-  const uint64_t need = (uint64_t)(4 + 2 * P.m) * dim;
+  const uint64_t need = (uint64_t)(6 + 2 * P.m) * dim;
   if (ctx->lbfgs_ws_floats < need) {
     ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->lbfgs_ws) ADMM_HIP_CHECK(hipFree(ctx->lbfgs_ws));
@@ -1276,7 +1284,8 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     if (!csr->d_dmargin) ADMM_HIP_CHECK(hipMalloc(&csr->d_dmargin, sizeof(float) * csr->nrows));
   }
   float *g = ctx->lbfgs_ws, *xp = g + dim, *gp = xp + dim, *d = gp + dim;
-  float *S = d + dim, *Y = S + (uint64_t)P.m * dim;
+  float *s_new = d + dim, *y_new = s_new + dim;  // the newest pair, before it is known to be usable
+  float *S = y_new + dim, *Y = S + (uint64_t)P.m * dim;
   std::vector<double> ys_hist(P.m, 0.0), alpha(P.m, 0.0);
   int head = 0, count = 0;  // ring: newest at (head-1) mod m
 
@@ -1496,13 +1505,16 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     ADMM_TRY(vec_dot(ctx, x, x, dim, &xx));
     ADMM_TRY(vec_dot(ctx, g, g, dim, &gg));
     if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) <= P.epsilon) break;
-    float *s_new = S + (uint64_t)head * dim, *y_new = Y + (uint64_t)head * dim;
     ADMM_TRY(vec_sub(ctx, s_new, x, xp, dim));
     ADMM_TRY(vec_sub(ctx, y_new, g, gp, dim));
     double ys = 0, yy = 0;
     ADMM_TRY(vec_dot(ctx, y_new, s_new, dim, &ys));
     ADMM_TRY(vec_dot(ctx, y_new, y_new, dim, &yy));
     if (ys > 1e-30) {
+      // only a pair with positive curvature enters the ring (a rejected one must not overwrite the
+      // oldest pair that is still in use)
+      ADMM_TRY(admm_vec_copy(ctx, S + (uint64_t)head * dim, s_new, dim));
+      ADMM_TRY(admm_vec_copy(ctx, Y + (uint64_t)head * dim, y_new, dim));
       ys_hist[head] = ys;
       head = (head + 1) % P.m;
       if (count < P.m) ++count;

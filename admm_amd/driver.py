@@ -157,7 +157,7 @@ class Worker:
         """src/workers.cc:51-87.  train_parts: the worker's data parts as capi.SampleSet."""
         if admm_params.local_solver == "lbfgs":
             assert len(train_parts) == 1, "the L-BFGS local solver takes one resident part"
-            return train_parts[0].lbfgs_solve(self.base_vec_, offset=None, z=global_weights,
+            return train_parts[0].lbfgs_solve(self.base_vec_, offset=self.bias_vec_, z=global_weights,
                                               ydual=self.langr_vec_, rho=admm_params.step_size,
                                               **admm_params.lbfgs)
         # FtrlSolver::Init zeroes w; z, n start from zt_vec_, nt_vec_ (src/workers.cc:64-67)
@@ -252,6 +252,8 @@ def global_test_metrics(ctx, test_set, groups):
     n = test_set.nrows
     off, total = adist.slice_of_rank(n)
     buf = torch.zeros(2 * max(total, 1), dtype=torch.float32, device="cuda")
+    # the zero fill runs on torch's current stream, the library writes on the context's own
+    torch.cuda.current_stream().synchronize()
     base = buf.data_ptr()
     if n:
         test_set.predict_into(groups, capi.DeviceVec.from_ptr(ctx, base + 4 * off, n))

@@ -75,7 +75,7 @@ int admm_vec_download(admm_ctx *ctx, float *dst_host, const float *src, uint64_t
  * dmlc::Row with value == NULL), label f32[nrows].  With add_bias != 0 every row gets the
  * (index 0, value 1) entry in front and all indices move up by one, on the device
  * (src/sample_set.cc:70-88); `dim` is the dimension AFTER that shift.  Column indices must be
- * < dim (checked, as dmlc's SDot CHECKs).  */
+ * < dim (checked, as dmlc's SDot CHECKs).  Limits: dim < 2^30, nrows < 2^32 - 1 per sample set. */
 int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint32_t *col, const float *val,
                     const float *label, uint64_t nrows, uint64_t nnz, uint64_t dim, int add_bias,
                     admm_csr **out);
@@ -135,7 +135,7 @@ int admm_metrics(admm_csr *csr, const float *const *groups, int ngroups, double 
  * AUC over n (score, label) pairs in DEVICE memory.  The reference reports one AUC per rank; a
  * job that wants the AUC of all ranks' test rows together gathers the ranks' scores and labels
  * (admm_predict into one rank's slice of a zero-filled buffer + a sum all-reduce does it) and
- * calls this once. */
+ * calls this once.  n < 2^31 (the sort's 32-bit positions); more rows are rejected. */
 int admm_auc_scores(admm_ctx *ctx, const float *scores, const float *labels, uint64_t n,
                     double *auc);
 /* Copies the nrows labels of the sample set (as stored: the file's labels, src/sample_set.cc:41)

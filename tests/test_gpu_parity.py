@@ -230,6 +230,47 @@ def test_ftrl_multi_pass_equals_single_passes(ctx):
         s.destroy()
 
 
+def test_ftrl_pass_relabel_pass(ctx, oracle):
+    """a row-by-row pass, then the frequency relabelling, then a second pass: the tables the first
+    pass built describe the old numbering and must not be reused"""
+    dim = 5000
+    raw = make_synth_csr(1200, dim, 25, seed=71)
+    tr = oracle.translate(raw)
+    rng = np.random.default_rng(2)
+    off = rng.normal(0, 0.02, dim).astype(np.float32)
+    reg = rng.normal(0, 0.02, dim).astype(np.float32)
+    prm = (0.05, 1.0, 0.1, 1.0)
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    dev = upload(ctx, raw, dim)
+    w, z, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    doff, dreg = ctx.vec(dim, off), ctx.vec(dim, reg)
+    dev.ftrl_pass(w, z, n, doff, dreg, *prm)
+    oracle.ftrl_run(tr, hw, hz, hn, off, reg, *prm)
+    dev.relabel_by_frequency()
+    dev.ftrl_pass(w, z, n, doff, dreg, *prm)
+    oracle.ftrl_run(tr, hw, hz, hn, off, reg, *prm)
+    for got, ref in ((w, hw), (z, hz), (n, hn)):
+        close(got.download(), ref, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    dev.destroy()
+
+
+def test_ftrl_minibatch_wide_column_block(ctx, oracle):
+    """col_block 4096 in the mini-batch form: 66 KB of LDS in the 512-thread transposed sweep"""
+    dim = 9000
+    raw = make_synth_csr(1500, dim, 25, seed=36)
+    tr = oracle.translate(raw)
+    prm = (0.05, 1.0, 0.2, 1.5)
+    zero = np.zeros(dim, np.float32)
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    oracle.ftrl_run(tr, hw, hz, hn, zero, zero, *prm, batch=500)
+    dev = upload(ctx, raw, dim).build_transposed(panel_rows=500, col_block=4096)
+    w, z, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    dev.ftrl_pass(w, z, n, ctx.vec(dim), ctx.vec(dim), *prm, batch=500)
+    for got, ref in ((w, hw), (z, hz), (n, hn)):
+        close(got.download(), ref, rtol=5e-5, atol=2e-6)
+    dev.destroy()
+
+
 @pytest.mark.parametrize("batch", [64, 500])
 def test_ftrl_minibatch(ctx, oracle, batch):
     dim = 301
