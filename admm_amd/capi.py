@@ -21,7 +21,7 @@ SYMBOLS = [
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
     "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_destroy",
     "admm_predict", "admm_metrics", "admm_auc_scores", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
-    "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus",
+    "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus", "admm_consensus_static",
     "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32",
 ]
 
@@ -102,6 +102,7 @@ def load():
         "admm_dual_update": [vp, vp, vp, vp, f32, u64],
         "admm_consensus": [vp, vp, i32, f32, f32, f32, vp, vp, vp, u64, C.POINTER(C.c_double),
                            C.POINTER(C.c_double)],
+        "admm_consensus_static": [vp, vp, i32, f32, f32, f32, vp, vp, vp, u64, vp],
         "admm_comm_unique_id": [vp],
         "admm_comm_init": [vp, i32, i32, vp],
         "admm_allreduce_sum_f32": [vp, vp, u64],
@@ -258,6 +259,15 @@ class Context:
                                      C.byref(r2) if want_residuals else None,
                                      C.byref(s2) if want_residuals else None))
         return (r2.value, s2.value) if want_residuals else None
+
+    def consensus_static(self, total, num_worker, rho, global_var, l1, x, ydual, z, residuals=None, stream=None,
+                         dim=None):
+        """admm_consensus_static: the same step without a context, a host wait or an allocation, on `stream`
+        (raw hipStream_t value, None = the default stream) of the current device; `residuals` is a device
+        buffer of two doubles or None"""
+        _check(self.L.admm_consensus_static(C.c_void_p(stream) if stream else None, total.ptr, num_worker, rho,
+                                            global_var, l1, x.ptr, ydual.ptr, z.ptr, x.n if dim is None else int(dim),
+                                            residuals.ptr if residuals is not None else None))
 
     def allreduce_sum(self, buf):
         _check(self.L.admm_allreduce_sum_f32(self.h, buf.ptr, buf.n))

@@ -2,6 +2,7 @@
 #include "internal.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace admm_impl {
 
@@ -130,6 +131,21 @@ __global__ void __launch_bounds__(256) k_dual_update(float *__restrict__ y,
     y[i] += rho * (x[i] - z[i]);
 }
 
+// one coordinate of the consensus step: z-update (src/master.cc:17, with the optional soft
+// threshold), dual update (src/workers.cc:117), and this coordinate's terms of the two residuals
+__device__ inline void consensus_elem(const float *__restrict__ sum, float denom, float l1, float rho,
+                                      const float *__restrict__ x, float *__restrict__ y,
+                                      float *__restrict__ z, uint64_t i, double &r2, double &s2) {
+  const float zo = z[i];
+  const float zn = soft_threshold(sum[i], l1) / denom;
+  const float xi = x[i];
+  z[i] = zn;
+  y[i] += rho * (xi - zn);
+  const double d = (double)xi - (double)zn, e = (double)zn - (double)zo;
+  r2 += d * d;
+  s2 += e * e;
+}
+
 // z-update + dual update + both residual partial sums in one pass over the dim-sized vectors.
 __global__ void __launch_bounds__(256) k_consensus(const float *__restrict__ sum, float denom,
                                                    float l1, float rho,
@@ -139,22 +155,91 @@ __global__ void __launch_bounds__(256) k_consensus(const float *__restrict__ sum
   __shared__ double sh[4];
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   double r2 = 0, s2 = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const float zo = z[i];
-    const float zn = soft_threshold(sum[i], l1) / denom;
-    const float xi = x[i];
-    z[i] = zn;
-    y[i] += rho * (xi - zn);
-    const double d = (double)xi - (double)zn, e = (double)zn - (double)zo;
-    r2 += d * d;
-    s2 += e * e;
-  }
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    consensus_elem(sum, denom, l1, rho, x, y, z, i, r2, s2);
   r2 = block_sum_256(r2, sh);
   s2 = block_sum_256(s2, sh);
   if (threadIdx.x == 0) {
     partials[0 * kMaxPartialBlocks + blockIdx.x] = r2;
     partials[1 * kMaxPartialBlocks + blockIdx.x] = s2;
   }
+}
+
+// ---- the consensus step for callers that may not allocate ------------------------------------
+//
+// Same arithmetic per coordinate; the per-workgroup residual partials go to a fixed array in the
+// code object's own device memory instead of a context's scratch allocation.  Workgroup b owns
+// coordinates [b * kStaticChunk, (b + 1) * kStaticChunk), so the partition (and with it the order
+// of the residual sums) does not depend on the GPU's CU count.
+constexpr uint32_t kStaticChunk = 4096;        // coordinates per workgroup
+constexpr uint32_t kStaticMaxBlocks = 65536;   // partial slots per residual: dim <= 2^28
+static_assert((uint64_t)kStaticChunk * kStaticMaxBlocks == ADMM_CONSENSUS_STATIC_MAX_DIM, "header and kernel disagree");
+// [0, kStaticMaxBlocks): partials of r2; [kStaticMaxBlocks, 2 kStaticMaxBlocks): partials of s2.
+// 1 MiB per GPU the library runs on, held until the process ends.  Host code never passes this
+// name to a kernel or a memory call: it is a host-side stand-in for the symbol, and each device
+// has its own copy at its own address, resolved once per device by static_scratch() below.
+static __device__ __align__(256) double scratch[2 * kStaticMaxBlocks];
+
+__global__ void __launch_bounds__(256) k_consensus_chunked(const float *__restrict__ sum, float denom,
+                                                           float l1, float rho,
+                                                           const float *__restrict__ x,
+                                                           float *__restrict__ y, float *__restrict__ z,
+                                                           uint64_t n, double *__restrict__ partials) {
+  __shared__ double sh[4];
+  const uint64_t base = (uint64_t)blockIdx.x * kStaticChunk;
+  const uint64_t end = base + kStaticChunk < n ? base + kStaticChunk : n;
+  double r2 = 0, s2 = 0;
+  for (uint64_t i = base + threadIdx.x; i < end; i += 256)
+    consensus_elem(sum, denom, l1, rho, x, y, z, i, r2, s2);
+  r2 = block_sum_256(r2, sh);
+  s2 = block_sum_256(s2, sh);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = r2;
+    partials[kStaticMaxBlocks + blockIdx.x] = s2;
+  }
+}
+
+// block 0: out[0] = sum of the r2 partials; block 1: out[1] = rho^2 * sum of the s2 partials.
+// Only the first nblocks slots of each half are read: what an earlier, larger call left behind
+// them is never looked at.
+__global__ void __launch_bounds__(256) k_finish_static(const double *__restrict__ partials, uint32_t nblocks,
+                                                       double rho2, double *__restrict__ out) {
+  __shared__ double sh[256];
+  const double *p = partials + (size_t)blockIdx.x * kStaticMaxBlocks;
+  double acc = 0;
+  for (uint32_t i = threadIdx.x; i < nblocks; i += 256) acc += p[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = blockIdx.x == 1 ? rho2 * sh[0] : sh[0];
+}
+
+// Device address of `scratch` on `device`, resolved once per device with that device current.
+constexpr int kMaxDevices = 64;
+static double *g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
+
+static int static_scratch(int device, double **out) {
+  ADMM_REQUIRE(device >= 0 && device < kMaxDevices, "device %d: at most %d devices per process", device, kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    int cur = -1;
+    ADMM_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != device) ADMM_HIP_CHECK(hipSetDevice(device));
+    double *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&ptr), HIP_SYMBOL(scratch));
+    if (cur != device) hipSetDevice(cur);
+    if (e != hipSuccess || !ptr) {
+      set_error("hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+      return ADMM_ERR_HIP;
+    }
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return ADMM_OK;
 }
 
 __global__ void __launch_bounds__(256) k_dot(const float *__restrict__ a,
@@ -252,6 +337,12 @@ extern "C" int admm_ctx_create(int device, void *stream, admm_ctx **out) {
   ADMM_REQUIRE(device >= 0 && device < ndev, "admm_ctx_create: device %d out of range (%d)", device,
                ndev);
   ADMM_HIP_CHECK(hipSetDevice(device));
+  {
+    // resolve this device's copy of the static scratch array now, so that a later
+    // admm_consensus_static on this device finds it without any runtime query
+    double *unused = nullptr;
+    ADMM_TRY(static_scratch(device, &unused));
+  }
   admm_ctx *ctx = new admm_ctx();
   ctx->device = device;
   hipDeviceProp_t prop;
@@ -432,6 +523,32 @@ extern "C" int admm_consensus(admm_ctx *ctx, const float *sum, int num_worker, f
     ADMM_TRY(finish_partials(ctx, 2, grid));
     if (r2) *r2 = ctx->h_scalars[0];
     if (s2) *s2 = (double)rho * (double)rho * ctx->h_scalars[1];
+  }
+  return ADMM_OK;
+}
+
+extern "C" int admm_consensus_static(void *stream, const float *sum, int num_worker, float rho,
+                                     float global_var, float l1, const float *x, float *ydual,
+                                     float *z, uint64_t dim, double *residuals_out) {
+  ADMM_REQUIRE(sum && x && ydual && z && dim > 0 && num_worker > 0, "admm_consensus_static: bad arguments");
+  ADMM_REQUIRE(dim <= ADMM_CONSENSUS_STATIC_MAX_DIM,
+               "admm_consensus_static: dim %llu exceeds the static scratch (at most %llu coordinates); "
+               "use admm_consensus",
+               (unsigned long long)dim, (unsigned long long)ADMM_CONSENSUS_STATIC_MAX_DIM);
+  int device = -1;
+  ADMM_HIP_CHECK(hipGetDevice(&device));
+  double *ptr = nullptr;  // this device's copy of `scratch`
+  ADMM_TRY(static_scratch(device, &ptr));
+  const float denom = num_worker * rho + global_var;  // src/master.cc:17, float arithmetic
+  const uint32_t nblocks = (uint32_t)((dim + kStaticChunk - 1) / kStaticChunk);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_consensus_chunked, dim3(nblocks), dim3(256), 0, s, sum, denom, l1, rho, x, ydual, z, dim,
+                     ptr);
+  ADMM_HIP_CHECK(hipGetLastError());
+  if (residuals_out) {
+    hipLaunchKernelGGL(k_finish_static, dim3(2), dim3(256), 0, s, static_cast<const double *>(ptr), nblocks,
+                       (double)rho * (double)rho, residuals_out);
+    ADMM_HIP_CHECK(hipGetLastError());
   }
   return ADMM_OK;
 }

@@ -220,6 +220,24 @@ int admm_consensus(admm_ctx *ctx, const float *sum, int num_worker, float rho, f
                    float l1, const float *x, float *ydual, float *z, uint64_t dim, double *r2,
                    double *s2);
 
+/* admm_consensus for callers that cannot allocate device memory or wait for the GPU: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
+ * in the reference.  Same update of z and ydual (bit for bit) and the same two residuals, but:
+ *   - no context: the work is queued on `stream` (a hipStream_t, NULL = the default stream) of the
+ *     calling thread's CURRENT device, and the call never synchronises;
+ *   - residuals_out is a DEVICE pointer to two doubles {r2, s2} written by the last kernel (NULL:
+ *     not wanted);
+ *   - the per-workgroup partial sums live in a fixed 1 MiB array inside the library's code object
+ *     (one copy per GPU, held until the process ends) instead of a context's scratch allocation,
+ *     which limits dim to ADMM_CONSENSUS_STATIC_MAX_DIM; a larger dim is rejected with
+ *     ADMM_ERR_INVALID and nothing is launched.
+ * The call makes no hipMalloc / hipFree and calls no allocating routine.  All calls on one GPU
+ * share that GPU's array: two calls that overlap on one GPU (different streams) race on it. */
+#define ADMM_CONSENSUS_STATIC_MAX_DIM (1ull << 28)
+int admm_consensus_static(void *stream, const float *sum, int num_worker, float rho,
+                          float global_var, float l1, const float *x, float *ydual, float *z,
+                          uint64_t dim, double *residuals_out);
+
 /* ---- collective (rabit::Allreduce<op::Sum>, src/admm_allreduce.cpp:69) -------------------- */
 
 /* RCCL communicator over the context's device.  unique_id: 128 bytes from
