@@ -59,7 +59,7 @@ constexpr int fw_threads(bool hasval) { return fw_consumers(hasval) + kFwProduce
 constexpr int kFwRowSlots = 128;
 constexpr int kFwChunk = 8192;
 constexpr int kFwHot = 16384;
-constexpr int kFwSlots = 4;                                  // tiles whose row data is resident in LDS
+constexpr int kFwSlots = 5;                                  // tiles whose row data is resident in LDS
 constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kFwSlots + 4) * kFwRowSlots) +
                           sizeof(unsigned long long) * (kFwSlots * (kFwRowSlots + 2) + kFwSlots * kFwRowSlots +
                                                         2 * kFwRowSlots * kWarmWords + 2 * 64 * kWarmWords + kWarmWords) + 64;
@@ -79,8 +79,10 @@ constexpr size_t kFwLds = sizeof(float) * (2 * kFwChunk + kFwHot + 8 * 256 + (kF
 //
 // A wave that issues loads stalls until the memory pipe has accepted them, so the waves that
 // feed the pipe do nothing else: while the consumers reduce tile i (product buffer half i & 1),
-// the producers issue the stream of tile i+2, make the products of tile i+1 in the other half,
-// wait, and meet the consumers at the barrier that ends the step.
+// the producers make the products of tile i+1 in the other half, issue the stream of tile i+3
+// behind that, wait for everything except that stream, and meet the consumers at the barrier that
+// ends the step.  A tile's stream is thus in flight for two whole steps (three register sets per
+// producer thread): its trip to HBM is never waited for.
 // The weights outside the LDS copy are fetched by exec-masked `buffer_load_dword ... lds`
 // instructions, which the memory pipe completes by writing LDS itself: lanes whose column is in
 // the LDS copy (or past the tile's end) are masked off and cost the pipe nothing, and no register
@@ -142,25 +144,38 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   // per-lane sums of the 64 mask columns over the rows this wave has seen (lane k <-> column k)
   unsigned long long h1 = 0, h2 = 0, hseen = 0;
 
-  // Producers keep two register sets of streamed entries, one dword per lane and load: entry
+  // Producers keep three register sets of streamed entries, one dword per lane and load: entry
   // j * kFwProducers + ptid of the tile's chunk, so that the 64 entries of one wave-wide load are
-  // consecutive in the product buffer.  X = the tile whose products are made next, Y = the one
-  // after it.
+  // consecutive in the product buffer.  Set t % 3 holds tile t: during step i one set holds tile
+  // i+1 (arrived; its products are made now), one tile i+2 (in flight), one receives tile i+3.
   constexpr int J = kFwChunk / kFwProducers;  // loads per producer thread and chunk
-  uint32_t xc[J], yc[J];
-  float xv[J], yv[J];  // sets with values only
+  uint32_t c0[J], c1[J], c2[J];
+  float v0[J], v1[J], v2[J];  // sets with values only
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    xc[j] = yc[j] = 0u;
-    xv[j] = yv[j] = 0.0f;
+    c0[j] = c1[j] = c2[j] = 0u;
+    v0[j] = v1[j] = v2[j] = 0.0f;
   }
+  // wait until only the loads of the newest stream (J, or 2 J with values) are outstanding
+  auto wait_all_but_newest_stream = [] {
+    if (HASVAL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * J) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J) : "memory");
+  };
+  static_assert(2 * J <= 63, "vmcnt holds six bits");
   const int pwave = __builtin_amdgcn_readfirstlane(ptid >> 6);
   // the gathered vector as a buffer resource (dim * 4 bytes)
   const uint64_t wbase = reinterpret_cast<uint64_t>(wsum);
   const u32x4 wres = {(uint32_t)wbase, (uint32_t)(wbase >> 32) & 0xFFFFu, a.dim * 4u, 0x00020000u};
   // Stream of one tile: its stored entries [B, E) (at most one chunk of them) through a buffer
   // resource that starts at the tile's first entry; lanes past the tile's end read zero.
-  auto issue_stream = [&](uint32_t (&pc)[J], float (&pv)[J], unsigned long long B, unsigned long long E) {
+  auto issue_stream = [&](uint32_t (&pc)[J], float (&pv)[J], unsigned long long Bv, unsigned long long Ev) {
+    // the extents are the same in every lane: tell the compiler, or it wraps each load in a loop
+    // over the distinct resources
+    auto uni = [](unsigned long long v) {
+      return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const unsigned long long B = uni(Bv), E = uni(Ev);
     const unsigned long long n = E - B < (unsigned long long)kFwChunk ? E - B : (unsigned long long)kFwChunk;
     const __amdgpu_buffer_rsrc_t rc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.col + B), 0, (int)(n * 4), 0x00020000);
@@ -221,7 +236,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
     return (int)((a.r1 - rb) < (uint64_t)rpt ? (a.r1 - rb) : (uint64_t)rpt);
   };
   // park the row data of the first tiles in their LDS slots
-  for (uint64_t i = 0; i < 3 && i < nmine; ++i) {
+  for (uint64_t i = 0; i < 4 && i < nmine; ++i) {
     const int slot = (int)(i % kFwSlots);
     const uint64_t rb = a.r0 + tile_of(i) * rpt;
     const int nr = tile_rows(tile_of(i));
@@ -240,23 +255,48 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
     if (nmine > 0) {
       const unsigned long long B = rp0[0], E = rp0[tile_rows(tile_of(0))];
       const uint32_t n0 = chunk_len(B, E);
-      issue_stream(yc, yv, B, E);
-      gather_tail(yc, prod0, n0);
-      hot_products(yc, yv, prod0, n0);
+      issue_stream(c0, v0, B, E);
+      gather_tail(c0, prod0, n0);
+      hot_products(c0, v0, prod0, n0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (HASVAL) scale_tail(yc, yv, prod0, n0);
+      if (HASVAL) scale_tail(c0, v0, prod0, n0);
     }
     if (nmine > 1) {
       const unsigned long long *rp = rp0 + 1 * (kFwRowSlots + 2);
-      issue_stream(xc, xv, rp[0], rp[tile_rows(tile_of(1))]);
+      issue_stream(c1, v1, rp[0], rp[tile_rows(tile_of(1))]);
+    }
+    if (nmine > 2) {
+      const unsigned long long *rp = rp0 + 2 * (kFwRowSlots + 2);
+      issue_stream(c2, v2, rp[0], rp[tile_rows(tile_of(2))]);
+      wait_all_but_newest_stream();  // tile 1 has arrived when step 0 starts, tile 2 stays in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
+  // Row data (row pointers, masks, labels, warm mask words) is copied from global memory straight
+  // into its LDS slot by LDS-direct loads, 64 consecutive dwords per wave-instruction: no register
+  // is involved, so nothing makes the compiler wait for these loads, and the producers' wait at
+  // the end of a step covers them (they are older than the stream that stays in flight).
+  auto dma64 = [&](const void *src, uint32_t nbytes, const void *lds_dst, int chunk) {
+    const uint32_t off = (uint32_t)(chunk * 64 + lane) * 4u;
+    if (off < nbytes) {
+      const uint64_t base = reinterpret_cast<uint64_t>(src);
+      const u32x4 res = {(uint32_t)base, (uint32_t)(base >> 32) & 0xFFFFu, nbytes, 0x00020000u};
+      const uint32_t dst = (uint32_t)(uintptr_t)lds_dst + (uint32_t)chunk * 256u;
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(off), "s"(dst), "s"(res)
+                   : "memory");
+    }
+  };
   __syncthreads();
   // The two roles run separate tile loops (same trip count, one barrier per tile each), so the
   // registers a producer keeps across tiles are not live in the consumers' code and vice versa.
   // The role is wave-uniform; readfirstlane lets the compiler branch on a scalar.
 #define FW_TILE_HEAD \
-    const int slot = (int)(i % kFwSlots), slot1 = (int)((i + 1) % kFwSlots), slot3 = (int)((i + 3) % kFwSlots); \
+    const int slot = (int)(i % kFwSlots), slot1 = (int)((i + 1) % kFwSlots), slot3 = (int)((i + 3) % kFwSlots), \
+              slot4 = (int)((i + 4) % kFwSlots); \
     const unsigned long long *rp = rp0 + slot * (kFwRowSlots + 2); \
     const unsigned long long *mask_s = mask0 + slot * kFwRowSlots; \
     float *prod = prod0 + (i & 1) * kFwChunk; \
@@ -264,11 +304,11 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
     const int nr = tile_rows(tile); \
     const unsigned long long B = rp[0], E = rp[nr]; \
     const unsigned long long cb0 = B; \
-    const bool has1 = i + 1 < nmine, has2 = i + 2 < nmine, has3 = i + 3 < nmine;
+    const bool has1 = i + 1 < nmine, has3 = i + 3 < nmine, has4 = i + 4 < nmine;
   // One producer step: while the consumers reduce tile i, make the products of tile i+1 (held in
-  // the X registers) and stream tile i+2 into the Y registers.
+  // the X registers) and stream tile i+3 into the Z registers (which held tile i).
   const bool gather_first = pwave < kFwProducers / 128;
-  auto produce = [&](uint64_t i, uint32_t (&pxc)[J], float (&pxv)[J], uint32_t (&pyc)[J], float (&pyv)[J]) {
+  auto produce = [&](uint64_t i, uint32_t (&pxc)[J], float (&pxv)[J], uint32_t (&pzc)[J], float (&pzv)[J]) {
     FW_TILE_HEAD
     (void)mask_s;
     (void)prod;
@@ -282,26 +322,30 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
         if (MODE == FWD_LBFGS && a.out2) a.out2[a.r0 + ptile * rpt + ptid] = out2_s0[ph + ptid];
       }
     }
-    // row data of the tile three ahead, parked in LDS at the end of the step: producer threads
-    // 0..128 fetch row pointers and labels, the next 128 the masks
-    unsigned long long pf = 0;
-    float pf_lab = 0.0f;
-    int nr3 = 0;
-    if (has3) {
-      const uint64_t rb3 = a.r0 + tile_of(i + 3) * rpt;
-      nr3 = tile_rows(tile_of(i + 3));
-      if (ptid <= nr3) pf = a.rowptr[rb3 + ptid];
-      else if (dense && ptid > kFwRowSlots && ptid - (kFwRowSlots + 1) < nr3) pf = a.hmask[rb3 + ptid - (kFwRowSlots + 1)];
-      if (ptid < nr3) pf_lab = a.label[rb3 + ptid];
+    // row data of the tile four ahead into its slot: 5 wave-loads of row pointers, 4 of masks, 2 of
+    // labels, dealt over the 8 producer waves (rows past the tile's end keep stale words, which no
+    // consumer reads)
+    if (has4) {
+      const uint64_t rb4 = a.r0 + tile_of(i + 4) * rpt;
+      const uint32_t nr4 = (uint32_t)tile_rows(tile_of(i + 4));
+#pragma unroll
+      for (int k0 = 0; k0 < 16; k0 += kFwProducers / 64) {
+        const int k = k0 + pwave;
+        if (k < 5) dma64(a.rowptr + rb4, (nr4 + 1) * 8u, rp0 + slot4 * (kFwRowSlots + 2), k);
+        else if (k < 9) { if (dense) dma64(a.hmask + rb4, nr4 * 8u, mask0 + slot4 * kFwRowSlots, k - 5); }
+        else if (k < 11) dma64(a.label + rb4, nr4 * 4u, lab0 + slot4 * kFwRowSlots, k - 9);
+      }
     }
-    // warm mask words of the next tile (needed by the consumers one step from now)
-    unsigned long long pf_warm = 0;
-    const int nw1 = (dense && has1) ? tile_rows(tile_of(i + 1)) * kWarmWords : 0;
-    if (ptid < nw1) pf_warm = a.hwarm[(a.r0 + tile_of(i + 1) * rpt) * kWarmWords + ptid];
-    // the stream of tile i+2 goes out first: it has the whole step to arrive
-    if (has2) {
-      const unsigned long long *rp2 = rp0 + (int)((i + 2) % kFwSlots) * (kFwRowSlots + 2);
-      issue_stream(pyc, pyv, rp2[0], rp2[tile_rows(tile_of(i + 2))]);
+    // warm mask words of the next tile (the consumers need them one step from now): 12 wave-loads
+    if (dense && has1) {
+      const uint64_t rb1 = a.r0 + tile_of(i + 1) * rpt;
+      const uint32_t nr1 = (uint32_t)tile_rows(tile_of(i + 1));
+#pragma unroll
+      for (int k0 = 0; k0 < 16; k0 += kFwProducers / 64) {
+        const int k = k0 + pwave;
+        if (k < 2 * kWarmWords * kFwRowSlots / 64)
+          dma64(a.hwarm + rb1 * kWarmWords, nr1 * (8u * kWarmWords), warm0 + ((i + 1) & 1) * kFwRowSlots * kWarmWords, k);
+      }
     }
     float *prodn = prod0 + ((i + 1) & 1) * kFwChunk;
     uint32_t n1 = 0;
@@ -319,39 +363,42 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
         gather_tail(pxc, prodn, n1);
       }
     }
+    // the stream of tile i+3 goes out last, so that the wait below can leave it in flight: it has
+    // this step's remainder and the two steps after it to arrive
+    if (has3) {
+      const unsigned long long *rp3 = rp0 + slot3 * (kFwRowSlots + 2);
+      issue_stream(pzc, pzv, rp3[0], rp3[tile_rows(tile_of(i + 3))]);
+    }
     // tiles whose rows are so long that they do not fit one chunk take extra passes by the
     // consumers, each bracketed by two barriers that both roles execute
     for (unsigned long long cb = cb0 + kFwChunk; cb < E; cb += kFwChunk) {
       __syncthreads();
       __syncthreads();
     }
-    // the gathers have landed in LDS after this wait (it also retires the stream issued above,
-    // which has had the whole step)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the gathers have landed in LDS after this wait, and so have the row data fetched above and
+    // the stream of tile i+2 (issued a step ago); only the stream issued just now stays in flight
+    if (has3) wait_all_but_newest_stream();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (HASVAL && has1) scale_tail(pxc, pxv, prodn, n1);
-    if (has3) {
-      if (ptid <= nr3) rp0[slot3 * (kFwRowSlots + 2) + ptid] = pf;
-      else if (ptid > kFwRowSlots && ptid <= 2 * kFwRowSlots) mask0[slot3 * kFwRowSlots + ptid - (kFwRowSlots + 1)] = pf;
-      if (ptid < kFwRowSlots) lab0[slot3 * kFwRowSlots + ptid] = pf_lab;
-    }
-    if (ptid < nw1) warm0[((i + 1) & 1) * kFwRowSlots * kWarmWords + ptid] = pf_warm;
     __syncthreads();
   };
   if (__builtin_amdgcn_readfirstlane(tid) >= kFwConsumers) {
-    // two steps per trip with the register sets swapped: no copies of registers that loads in
+    // three steps per trip with the register sets rotated: no copies of registers that loads in
     // flight are still writing
-    for (uint64_t i = 0; i < nmine; i += 2) {
-      produce(i, xc, xv, yc, yv);
-      if (i + 1 < nmine) produce(i + 1, yc, yv, xc, xv);
+    for (uint64_t i = 0; i < nmine; i += 3) {
+      produce(i, c1, v1, c0, v0);
+      if (i + 1 < nmine) produce(i + 1, c2, v2, c1, v1);
+      if (i + 2 < nmine) produce(i + 2, c0, v0, c2, v2);
     }
   } else {
   for (uint64_t i = 0; i < nmine; ++i) {
     FW_TILE_HEAD
     (void)slot1;
     (void)slot3;
+    (void)slot4;
     (void)has1;
-    (void)has2;
     (void)has3;
+    (void)has4;
     {
       // ---- consumers --------------------------------------------------------------------------
       float rowsum = 0.0f;

@@ -18,10 +18,12 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--no-gather", action="store_true")
 ap.add_argument("--explicit-values", action="store_true")
 ap.add_argument("--no-relabel", action="store_true")
+ap.add_argument("--heavy", action="store_true", help="log-normal row lengths (sigma 1.2, up to 1024 draws)")
 args = ap.parse_args()
 
 ctx = capi.Context(0)
-s = ctx.csr_synth(args.rows, args.dim, args.draws, seed=1, explicit_values=args.explicit_values)
+kw = dict(len_dist=1, tail_sigma=1.2, max_len=1024) if args.heavy else {}
+s = ctx.csr_synth(args.rows, args.dim, args.draws, seed=1, explicit_values=args.explicit_values, **kw)
 s.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
 if not args.no_relabel:
     s.relabel_by_frequency()
