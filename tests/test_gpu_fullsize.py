@@ -208,3 +208,50 @@ def test_heavy_tailed_rows_over_sixteen_million_features():
     a.destroy()
     b.destroy()
     ctx.close()
+
+
+def test_heavy_tailed_rows_over_sixteen_million_features_against_the_oracle():
+    """The Criteo-like shape (2^24 hashed features, log-normal row lengths with rows of many hundred
+    entries among short ones) at a size the CPU restatement still handles in seconds: objective and
+    gradient, predictions, logloss and AUC, the row-by-row FTRL pass and the mini-batch one, each
+    against the oracle on the downloaded sample set."""
+    from admm_amd import capi
+    from oracle import oracle as orc
+    orc.build()
+    ctx = capi.Context(0)
+    dim = 1 << 24
+    dev = ctx.csr_synth(400_000, dim, 40, seed=31, len_dist=1, tail_sigma=1.2, max_len=1024)
+    dev.build_transposed(panel_rows=100_000, col_block=8192).relabel_by_frequency()
+    tr = orc.Csr(*dev.download(), dim)
+    lens = np.diff(tr.rowptr.astype(np.int64))
+    assert tr.nnz == dev.nnz and lens.max() > 8 * lens.mean() and lens.min() >= 1
+    rng = np.random.default_rng(2)
+    x = (rng.normal(0, 0.3, dim) * (rng.random(dim) < 0.05)).astype(np.float32)
+    x[:4096] = rng.normal(0, 0.1, 4096)
+    b = (rng.normal(0, 0.05, dim) * (rng.random(dim) < 0.01)).astype(np.float32)
+    z = (rng.normal(0, 0.1, dim) * (rng.random(dim) < 0.05)).astype(np.float32)
+    dx, db, dz = ctx.vec(dim, x), ctx.vec(dim, b), ctx.vec(dim, z)
+    # objective and gradient
+    f_ref, g_ref = orc.logistic_fg(tr, dim, x, b, z, None, 0.05)
+    g = ctx.vec(dim)
+    f = dev.logistic_fg(dx, g, offset=db, z=dz, rho=0.05)
+    assert f == pytest.approx(f_ref, rel=1e-5)
+    np.testing.assert_allclose(g.download(), g_ref, rtol=2e-5, atol=2e-5 * np.abs(g_ref).max())
+    # predictions, logloss, AUC
+    s64, p_ref = orc.logloss_sum_f64(tr, [x, b], want_p=True)
+    np.testing.assert_allclose(dev.predict([dx, db]), p_ref, rtol=1e-5, atol=1e-6)
+    ll, auc, n = dev.metrics([dx, db])
+    assert n == tr.nrows and ll == pytest.approx(s64 / tr.nrows, rel=1e-5)
+    assert auc == pytest.approx(orc.auc_from_scores(p_ref, tr.label, f64=True), rel=1e-5)
+    # FTRL: the reference's row-by-row pass (hyper-parameters of script/start.sh), then one mini-batch pass
+    for batch, rtol in ((1, 1e-5), (100_000, 5e-5)):
+        hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+        orc.ftrl_run(tr, hw, hz, hn, b, z, 0.01, 1.0, 0.4, 2.5, batch=batch)
+        w, zz, nn = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+        dev.ftrl_pass(w, zz, nn, db, dz, 0.01, 1.0, 0.4, 2.5, batch=batch)
+        for got, ref in ((w, hw), (zz, hz), (nn, hn)):
+            np.testing.assert_allclose(got.download(), ref, rtol=rtol, atol=1e-6 * max(1.0, np.abs(ref).max()))
+        for v in (w, zz, nn):
+            v.free()
+    dev.destroy()
+    ctx.close()

@@ -203,6 +203,39 @@ def test_three_workers_under_the_local_launcher(tmp_path, oracle):
     assert float(alls[-1][1]) == pytest.approx(want, rel=5e-5)
 
 
+def test_wtest_in_three_psid_directories_under_the_launcher(tmp_path):
+    """the reference's plumbing case as it is worded: test/wtest.libsvm replicated into the
+    directories of three psids, `dmlc_local.py -n 3 ./admm admm.conf <train> <test> <out>`.  Every
+    rank reports the zero-weight logloss on its one test row in each of the three iterations (one
+    positive row: the reference's AUC formula divides by zero there, src/metrics.cc:80, so that
+    field is not a number), and ends in the state a single FTRL step from zero leaves."""
+    names = ["A", "B", "C"]
+    fixture = open(os.path.join(GOLDEN, "wtest.libsvm")).read()
+    for name in names:
+        for d in ("train", "test"):
+            os.makedirs(tmp_path / d / (name + "_aggregated"))
+            (tmp_path / d / (name + "_aggregated") / "part-00000").write_text(fixture)
+    os.makedirs(tmp_path / "out")
+    conf = tmp_path / "admm.conf"
+    conf.write_text("step_size = 0.01\nbias_var = 0.01\nglobal_var = 4\nftrl_alpha = 0.1\npasses = 3\ndim = 6\n"
+                    "A : 1\nB : 1\nC : 1\n")
+    out = _run([os.path.join(ROOT, "tools", "dmlc_local.py"), "-n", "3", "--allreduce", "shm",
+                os.path.join(BIN, "admm"), str(conf), str(tmp_path / "train"), str(tmp_path / "test"),
+                str(tmp_path / "out")])
+    for name in names:
+        lines = re.findall(r"^%s \| 0\.6931472 \| (\S+) \| 1$" % name, out, flags=re.M)
+        assert len(lines) == 3, out
+        assert all(not np.isfinite(float(a)) for a in lines)
+        x, bias, y, nt, zt = _read_sparse_sections(tmp_path / "out" / ("admm_weight_" + name))
+        assert not x.any() and not y.any() and not bias.any()
+        assert nt[[0, 1, 3, 5]].tolist() == [0.25] * 4 and zt[[0, 1, 3, 5]].tolist() == [-0.5] * 4
+        assert not nt[[2, 4]].any() and not zt[[2, 4]].any()
+        assert open(tmp_path / "out" / (name + ".bin")).read() == "-1:0\n"
+        g = open(tmp_path / "out" / ("global_params_" + name)).read().split("\n")
+        assert [float(v) for v in g[:4]] == [0.01, 4.0, 0.01, 6.0] and not [l for l in g[4:] if l]
+    assert [int(x) for x in re.findall(r"^Finish (\d+)-th iteration$", out, flags=re.M)] == [0, 1, 2]
+
+
 def test_launcher_restarts_on_254_and_reports_failures(tmp_path):
     """the keep-alive contract of the reference's launcher: exit code 254 means "start me again"; this
     part needs no GPU work, the workers are shell one-liners"""

@@ -75,6 +75,25 @@ def test_admm_wtest_state(oracle, known):
         assert r["lines"][0][2] == 1
 
 
+def test_reference_worker_test_expectations(oracle):
+    """test/worker_test.cc:47-63 of the reference: after one local update on test/wtest.libsvm the
+    payload is all zero, the consensus vector computed from it is all zero, and the payload after the
+    dual update is all zero again (Init(1, 1, 1, ...): step_size = bias_var = global_var = 1).  The
+    reference's test sizes the vectors with 5, one short of what its own bias shift needs for the
+    fixture's index 4; 6 is used here."""
+    _, tr = _wtest(oracle)
+    dim = 6
+    conf = oracle.AdmmConf(step_size=1.0, global_var=1.0, ftrl_alpha=1.0, passes=1, dim=dim, bias_var=1.0)
+    wk, zg = oracle.WorkerState(dim), np.zeros(dim, np.float32)
+    oracle.base_update(wk, [tr], conf, zg)                                   # :39
+    result = oracle.payload(wk.x, wk.y, conf.step_size)                      # :44
+    assert not result.any()                                                  # :46-47
+    zg = oracle.global_update(result, 1, conf.step_size, conf.global_var)    # :50
+    assert not zg.any()                                                      # :53-54
+    oracle.dual_update(wk.y, wk.x, zg, conf.step_size)                       # :57
+    assert not oracle.payload(wk.x, wk.y, conf.step_size).any()              # :59-62
+
+
 def test_batch1_equals_sequential(oracle):
     raw = make_synth_csr(300, 64, 6, seed=3)
     tr = oracle.translate(raw)
