@@ -19,10 +19,11 @@ SYMBOLS = [
     "admm_vec_alloc", "admm_vec_free", "admm_vec_zero", "admm_vec_copy", "admm_vec_upload",
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
-    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_destroy",
+    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_layout_bytes",
+    "admm_csr_destroy",
     "admm_predict", "admm_metrics", "admm_auc_scores", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus", "admm_consensus_static",
-    "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32",
+    "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32", "admm_comm_selftest",
 ]
 
 K_FORWARD, K_TRANSPOSED, K_FTRL_SEQ, K_ELEMENTWISE, K_FORWARD_EVAL = 0, 1, 2, 3, 4
@@ -86,6 +87,7 @@ def load():
         "admm_csr_build_transposed": [vp, u64, C.c_uint32],
         "admm_csr_relabel_by_frequency": [vp],
         "admm_csr_bytes": [vp, C.POINTER(u64), C.POINTER(u64)],
+        "admm_csr_layout_bytes": [vp, C.POINTER(u64)],
         "admm_csr_destroy": [vp],
         "admm_predict": [vp, C.POINTER(vp), i32, vp],
         "admm_metrics": [vp, C.POINTER(vp), i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -106,6 +108,7 @@ def load():
         "admm_comm_unique_id": [vp],
         "admm_comm_init": [vp, i32, i32, vp],
         "admm_allreduce_sum_f32": [vp, vp, u64],
+        "admm_comm_selftest": [vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -174,6 +177,7 @@ class Context:
         _check(self.L.admm_ctx_create(int(device), C.c_void_p(stream) if stream else None,
                                       C.byref(h)))
         self.h = h
+        self.rank, self.world = 0, 1
 
     def close(self):
         if self.h:
@@ -269,8 +273,23 @@ class Context:
                                             global_var, l1, x.ptr, ydual.ptr, z.ptr, x.n if dim is None else int(dim),
                                             residuals.ptr if residuals is not None else None))
 
-    def allreduce_sum(self, buf):
-        _check(self.L.admm_allreduce_sum_f32(self.h, buf.ptr, buf.n))
+    def allreduce_sum(self, buf, n=None):
+        """rabit::Allreduce<op::Sum> (src/admm_allreduce.cpp:69): in-place float sum over ranks on RCCL"""
+        _check(self.L.admm_allreduce_sum_f32(self.h, buf.ptr, buf.n if n is None else int(n)))
+
+    def comm_unique_id(self):
+        """128 bytes that rank 0 hands to every rank (admm_comm_unique_id)"""
+        buf = C.create_string_buffer(128)
+        _check(self.L.admm_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id=None):
+        self.rank, self.world = int(rank), int(world)
+        _check(self.L.admm_comm_init(self.h, self.rank, self.world,
+                                     C.create_string_buffer(unique_id, 128) if unique_id else None))
+
+    def comm_selftest(self):
+        _check(self.L.admm_comm_selftest(self.h))
 
 
 class SampleSet:
@@ -308,6 +327,12 @@ class SampleSet:
         a, b = C.c_uint64(), C.c_uint64()
         _check(self.ctx.L.admm_csr_bytes(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def layout_bytes(self):
+        """dict of HBM bytes by layout: row_major, forward_form, column_block_copy, row_vectors"""
+        out = (C.c_uint64 * 4)()
+        _check(self.ctx.L.admm_csr_layout_bytes(self.h, out))
+        return dict(zip(("row_major", "forward_form", "column_block_copy", "row_vectors"), [int(v) for v in out]))
 
     def _groups(self, groups):
         arr = (C.c_void_p * len(groups))(*[g.ptr.value for g in groups])

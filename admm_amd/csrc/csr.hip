@@ -540,6 +540,17 @@ extern "C" int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t
   return ADMM_OK;
 }
 
+extern "C" int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]) {
+  ADMM_REQUIRE(csr && out, "admm_csr_layout_bytes: NULL argument");
+  const uint64_t n = csr->nrows;
+  out[0] = 8 * (n + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * n;
+  out[1] = csr->hot_dense ? 8 * (n + 1) + 8 * n * (1 + kWarmWords) + 4 * csr->cnnz + (csr->d_cval ? 4 * csr->cnnz : 0) + 4 * n
+                          : out[0];
+  out[2] = csr->has_t ? 8 * (csr->npanels * csr->nblocks + 1) + 6 * csr->tnnz + (csr->d_tval ? 4 * csr->tnnz : 0) : 0;
+  out[3] = (csr->d_rowbuf ? 4 * n : 0) + (csr->d_margin ? 4 * n : 0) + (csr->d_dmargin ? 4 * n : 0);
+  return ADMM_OK;
+}
+
 extern "C" int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, float *val,
                                  float *label) {
   ADMM_REQUIRE(csr, "admm_csr_download: csr is NULL");

@@ -22,10 +22,43 @@ def init(backend=None, device=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
-        if backend == "nccl" and device is not None:
+        if backend == "nccl" and device is not None:  # (a mixed "cpu:gloo,cuda:nccl" group takes no device id)
             kw["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def lib_comm_init(ctx):
+    """The communicator of libadmm_hip.so over all ranks (the product's all-reduce path: RCCL over
+    xGMI behind admm_allreduce_sum_f32).  Rank 0 draws the 128-byte id; the other ranks receive it
+    through the torch.distributed process group when one is up (host data, any backend), else through a
+    file under ADMM_RENDEZVOUS_DIR keyed by MASTER_PORT / DMLC_TRACKER_PORT, as the C++ programs do."""
+    rank, world, _ = env_rank_world()
+    if world == 1:
+        ctx.comm_init(0, 1)
+        return rank, world
+    uid = ctx.comm_unique_id() if rank == 0 else None
+    if dist.is_initialized():
+        box = [uid]
+        dist.broadcast_object_list(box, src=0, device=torch.device("cpu"))
+        uid = box[0]
+    else:
+        import time
+        job = os.environ.get("MASTER_PORT", os.environ.get("DMLC_TRACKER_PORT", "local"))
+        path = os.path.join(os.environ.get("ADMM_RENDEZVOUS_DIR", "/tmp"), "admm_uid_py_%s" % job)
+        if rank == 0:
+            with open(path + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(path + ".tmp", path)
+        else:
+            for _ in range(6000):
+                if os.path.exists(path) and os.path.getsize(path) == 128:
+                    break
+                time.sleep(0.1)
+            with open(path, "rb") as f:
+                uid = f.read()
+    ctx.comm_init(rank, world, uid)
+    return rank, world
 
 
 def shard_range(total_rows, rank, world):

@@ -242,30 +242,116 @@ def admm_iteration(worker, master, train_parts, test_set, admm_params, global_we
     return dict(line=line, r2=r2, s2=s2, stats=stats)
 
 
+# floats appended to the payload buffer of AdmmLoop: this rank's r2 and s2 of the previous iteration, each
+# as a (high, low) pair of floats, so that the iteration's one all-reduce also sums the residuals
+RESIDUAL_TAIL = 4
+
+
+def _split(v):
+    hi = np.float32(v)
+    return hi, np.float32(v - float(hi))
+
+
+class AdmmLoop:
+    """The loop of src/admm_allreduce.cpp:55-91 for one rank, with the primal and dual residuals of ALL
+    ranks as a by-product of its one all-reduce: `payload` holds dim + RESIDUAL_TAIL floats, the tail
+    carries this rank's r2 = |x - z|^2 and s2 = rho^2 |z - z_prev|^2 of the PREVIOUS iteration (they
+    need the z that the all-reduce produces, so they travel one iteration behind), and after the
+    all-reduce the tail holds their sums over ranks.  `allreduce(payload)` sums the whole buffer in
+    place.  global_residuals[k] = (sum over ranks of r2, s2) of iteration k."""
+
+    def __init__(self, worker, master, train_parts, test_set, admm_params, global_weights, payload, allreduce, world):
+        self.worker, self.master, self.parts, self.test = worker, master, train_parts, test_set
+        self.prm, self.zg, self.payload, self.allreduce, self.world = admm_params, global_weights, payload, allreduce, world
+        self.dim = worker.dim
+        assert payload.n >= self.dim + RESIDUAL_TAIL
+        self.tail = capi.DeviceVec.from_ptr(worker.ctx, payload.ptr.value + 4 * self.dim, RESIDUAL_TAIL)
+        self.pending = None
+        self.global_residuals = []
+
+    def _tail_up(self):
+        t = np.zeros(RESIDUAL_TAIL, np.float32)
+        if self.pending is not None:
+            t[0], t[1] = _split(self.pending[0])
+            t[2], t[3] = _split(self.pending[1])
+        self.tail.upload(t)
+
+    def _tail_down(self):
+        if self.pending is None:
+            return
+        t = self.tail.download().astype(np.float64)
+        self.global_residuals.append((t[0] + t[1], (t[2] + t[3]) / self.world))   # every rank holds the same s2
+        self.pending = None
+
+    def iteration(self, last=False):
+        wk, prm = self.worker, self.prm
+        if last:
+            wk.load = True                                        # :60-61
+        stats = wk.BaseUpdate(self.parts, prm, self.zg)           # :66
+        wk.GetWeights(prm, self.payload)                          # :67 (the first dim floats)
+        self._tail_up()
+        self.allreduce(self.payload)                              # :69
+        self._tail_down()
+        line = None
+        if self.test is not None:                                 # :76-81
+            line = self.test.metrics([wk.base_vec_, wk.bias_vec_])
+        r2, s2 = wk.ctx.consensus(self.payload, self.world, prm.step_size, prm.global_var, prm.global_l1,
+                                  wk.base_vec_, wk.langr_vec_, self.zg)        # :84-85 in one kernel
+        self.pending = (r2, s2)
+        return dict(line=line, r2=r2, s2=s2, stats=stats)
+
+    def flush_residuals(self):
+        """one more (small) exchange for the last iteration's pair; returns the last iteration's
+        residual norms over all ranks"""
+        if self.pending is not None:
+            self.payload.zero()
+            self._tail_up()
+            self.allreduce(self.payload)
+            self._tail_down()
+        if not self.global_residuals:
+            return None
+        r2, s2 = self.global_residuals[-1]
+        return {"primal_r": float(np.sqrt(r2)), "dual_s": float(np.sqrt(s2)), "r2_sum_over_ranks": r2, "s2": s2,
+                "iterations_recorded": len(self.global_residuals)}
+
+
 def global_test_metrics(ctx, test_set, groups):
     """Logloss and AUC over the test rows of ALL ranks (the reference reports them per rank only,
-    src/admm_allreduce.cpp:76-81): every rank predicts into its slice of a zero-filled buffer and
-    copies its labels into a second one, a sum all-reduce concatenates them, and every rank then
-    runs the device AUC (src/metrics.cc:14-89) once over the whole.  Returns (logloss, auc, rows)."""
-    import torch
-    from . import capi, dist as adist
+    src/admm_allreduce.cpp:76-81), on the library's own all-reduce (ctx.comm_init; one rank: no
+    exchange): row counts and loss sums travel as floats in two halves each, every rank predicts into
+    its slice of a zero-filled buffer and copies its labels into a second one, a sum all-reduce
+    concatenates them, and every rank then runs the device AUC (src/metrics.cc:14-89) once over the
+    whole.  Collective: every rank calls it.  Returns (logloss, auc, rows).  Same steps as
+    Metrics::AllRanks of the C++ programs."""
+    rank, world = ctx.rank, ctx.world
     n = test_set.nrows
-    off, total = adist.slice_of_rank(n)
-    buf = torch.zeros(2 * max(total, 1), dtype=torch.float32, device="cuda")
-    # the zero fill runs on torch's current stream, the library writes on the context's own
-    torch.cuda.current_stream().synchronize()
-    base = buf.data_ptr()
+    lsum = 0.0
+    if n:
+        loss_local, _, _ = test_set.metrics(groups, want_auc=False)
+        lsum = loss_local * n
+    meta = np.zeros(4 * world, np.float32)
+    meta[4 * rank + 0] = n >> 20
+    meta[4 * rank + 1] = n & 0xFFFFF
+    meta[4 * rank + 2] = np.float32(lsum)
+    meta[4 * rank + 3] = np.float32(lsum - float(meta[4 * rank + 2]))
+    dmeta = ctx.vec(4 * world, meta)
+    ctx.allreduce_sum(dmeta)
+    meta = dmeta.download().astype(np.float64)
+    dmeta.free()
+    counts = [(int(meta[4 * r]) << 20) + int(meta[4 * r + 1]) for r in range(world)]
+    total, off = sum(counts), sum(counts[:rank])
+    ltotal = float(sum(meta[4 * r + 2] + meta[4 * r + 3] for r in range(world)))
+    half = max(total, 1)
+    buf = ctx.vec(2 * half)                      # zero-filled on the context's stream: [scores | labels]
+    base = buf.ptr.value
     if n:
         test_set.predict_into(groups, capi.DeviceVec.from_ptr(ctx, base + 4 * off, n))
-        test_set.copy_labels(capi.DeviceVec.from_ptr(ctx, base + 4 * (max(total, 1) + off), n))
-    ctx.sync()
-    adist.gather_slices_(buf, off, n)
-    torch.cuda.synchronize()
-    loss_local, _, _ = test_set.metrics(groups, want_auc=False) if n else (0.0, None, 0)
-    sums = adist.allreduce_sum_(torch.tensor([loss_local * n, float(n)], dtype=torch.float64, device="cuda"))
+        test_set.copy_labels(capi.DeviceVec.from_ptr(ctx, base + 4 * (half + off), n))
+    ctx.allreduce_sum(buf)
     auc = ctx.auc_scores(capi.DeviceVec.from_ptr(ctx, base, total),
-                         capi.DeviceVec.from_ptr(ctx, base + 4 * max(total, 1), total), total)
-    return float(sums[0] / sums[1]), auc, total
+                         capi.DeviceVec.from_ptr(ctx, base + 4 * half, total), total) if total else float("nan")
+    buf.free()
+    return (ltotal / total if total else 0.0), auc, total
 
 
 def format_line(psid, loss, auc, n):

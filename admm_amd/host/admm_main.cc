@@ -50,14 +50,42 @@ int main(int argc, char *argv[]) {
 
     const int max_iter = prm.passes;
     const std::size_t dim = prm.dim;
-    ::admm::DeviceVector tmp(dim);
+    // The payload buffer carries four more floats: this rank's residual sums |x - z|^2 and
+    // rho^2 |z - z_prev|^2 of the PREVIOUS iteration (they need the z the all-reduce produces), each as a
+    // (high, low) pair, so that the iteration's one all-reduce also yields the residuals over all ranks.
+    constexpr std::size_t kTail = 4;
+    ::admm::DeviceVector tmp(dim + kTail);
+    double pend_r2 = 0, pend_s2 = 0;
+    bool pending = false;
+    auto tail_up = [&]() {
+      float t[kTail] = {0, 0, 0, 0};
+      if (pending) {
+        t[0] = (float)pend_r2;
+        t[1] = (float)(pend_r2 - (double)t[0]);
+        t[2] = (float)pend_s2;
+        t[3] = (float)(pend_s2 - (double)t[2]);
+      }
+      ADMM_CALL(admm_vec_upload(rt.ctx(), tmp.data() + dim, t, kTail));
+    };
+    auto tail_down = [&](int iter) {
+      if (!pending) return;
+      float t[kTail];
+      ADMM_CALL(admm_vec_download(rt.ctx(), t, tmp.data() + dim, kTail));
+      const double r2 = (double)t[0] + (double)t[1];
+      const double s2 = ((double)t[2] + (double)t[3]) / rt.GetWorldSize();  // every rank holds the same s2
+      if (rt.GetRank() == 0)
+        rt.TrackerPrintf("[residual-all] %d %.7e %.7e\n", iter, std::sqrt(r2), std::sqrt(s2));
+      pending = false;
+    };
 
     for (int r = 0; r < max_iter; ++r) {
       if (r == max_iter - 1) worker.load = true;
       // the prepare step of rabit::Allreduce (lazy_ftrl), then the reduction itself
       worker.BaseUpdate(train_unused, test_set, prm);
       worker.GetWeights(prm, tmp);
-      rt.AllreduceSum(tmp.data(), dim);
+      tail_up();
+      rt.AllreduceSum(tmp.data(), dim + kTail);
+      tail_down(r - 1);
 
       if (have_test) {
         std::vector<const ::admm::DeviceVector *> group_w = {&worker.base_vec_, &worker.bias_vec_};
@@ -76,7 +104,15 @@ int main(int argc, char *argv[]) {
       double r2 = 0, s2 = 0;  // GlobalUpdate + LangrangeUpdate, fused
       ADMM_CHECK(master_processor.Consensus(tmp, prm, rt.GetWorldSize(), worker, &r2, &s2));
       rt.TrackerPrintf("[residual] %s %d %.7e %.7e\n", worker.psid_.c_str(), r, std::sqrt(r2), std::sqrt(s2));
+      pend_r2 = r2;
+      pend_s2 = s2;
+      pending = true;
       if (rt.GetRank() == 0) rt.TrackerPrintf("Finish %d-th iteration\n", r);
+    }
+    if (pending) {  // the last iteration's residuals over all ranks: one more exchange of the tail alone
+      tail_up();
+      rt.AllreduceSum(tmp.data() + dim, kTail);
+      tail_down(max_iter - 1);
     }
 
     local_model.SaveState(prm.output_path + "/admm_weight_" + worker.psid_);

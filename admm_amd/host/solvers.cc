@@ -97,9 +97,9 @@ void Worker::LangrangeUpdate(const AdmmConfig &admm_params) {
 }
 
 void Worker::GetWeights(AdmmConfig &admm_params, DeviceVector &out) const {
-  ADMM_CHECK(out.size() == base_vec_.size());
+  ADMM_CHECK(out.size() >= base_vec_.size());  // the main loop keeps a few floats of its own behind the payload
   ADMM_CALL(admm_payload(Runtime::Get().ctx(), base_vec_.data(), langr_vec_.data(), admm_params.step_size, out.data(),
-                         out.size()));
+                         base_vec_.size()));
 }
 
 bool Master::GlobalUpdate(const DeviceVector &workers, AdmmConfig &admm_params, int num_worker) {
@@ -112,7 +112,7 @@ bool Master::Consensus(const DeviceVector &workers, AdmmConfig &admm_params, int
                        double *s2) {
   return admm_consensus(Runtime::Get().ctx(), workers.data(), num_worker, admm_params.step_size,
                         admm_params.global_var, admm_params.global_l1, worker.base_vec_.data(),
-                        worker.langr_vec_.data(), admm_params.global_weights.data(), workers.size(), r2,
+                        worker.langr_vec_.data(), admm_params.global_weights.data(), worker.base_vec_.size(), r2,
                         s2) == ADMM_OK;
 }
 

@@ -118,6 +118,11 @@ int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_b
 int admm_csr_relabel_by_frequency(admm_csr *csr);
 /* Bytes of HBM held by this sample set. */
 int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t *transposed_bytes);
+/* The same, by layout: out[0] the row-major CSR, out[1] the form the forward sweep streams (for a
+ * relabelled set the compact form: row masks of the most frequent columns + the remaining entries
+ * as CSR + labels; else the CSR itself), out[2] the column-block copy the transposed sweep streams,
+ * out[3] the per-row work vectors allocated so far. */
+int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]);
 int admm_csr_destroy(admm_csr *csr);
 
 /* ---- metrics (Metrics, src/metrics.cc:45-117) --------------------------------------------- */
@@ -247,6 +252,12 @@ int admm_comm_init(admm_ctx *ctx, int rank, int world, const void *unique_id_128
 /* In-place fp32 sum over ranks on the context's stream (world 1 without a communicator is a
  * no-op, as rabit's single-process mode). */
 int admm_allreduce_sum_f32(admm_ctx *ctx, float *buf, uint64_t n);
+/* Self-test of the RCCL binding, in the place of the reference's rabit smoke program
+ * (src/admm_main.cpp:37-52).  Creates a one-rank communicator of its own on the context's device
+ * and runs a sum all-reduce through it (works on a single GPU); with a communicator over more than
+ * one rank it also checks a sum of rank-dependent values through that one (collective: every rank
+ * calls it).  Synchronises the stream. */
+int admm_comm_selftest(admm_ctx *ctx);
 
 #ifdef __cplusplus
 }

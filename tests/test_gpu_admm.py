@@ -123,3 +123,36 @@ def test_admm_lbfgs_mode(ctx, oracle):
     rec_gpu, _ = _run_gpu(ctx, raws_train, raws_test, conf, dim)
     # both local solves run to convergence; iterates agree to the solver tolerance
     _compare(rec_gpu, rec_ref, rtol=5e-3, atol=2e-3, line_rel=1e-3, auc_rel=1e-3, res_rel=5e-2)
+
+
+def test_rccl_binding_selftest_and_loop_with_residual_tail(ctx, oracle):
+    """admm_comm_selftest on one GPU (a one-rank communicator of its own: library loading, unique id,
+    ncclCommInitRank, ncclAllReduce's type and operator codes), and driver.AdmmLoop -- the loop that
+    carries the residuals in the payload's tail -- against the reference loop for one rank"""
+    from admm_amd import driver
+    ctx.comm_init(0, 1)
+    ctx.comm_selftest()
+    dim = 211
+    raw_train, raw_test = make_synth_csr(900, dim, 11, seed=90), make_synth_csr(200, dim, 11, seed=91)
+    conf = oracle.AdmmConf(step_size=0.01, global_var=4.0, ftrl_alpha=0.1, passes=3, dim=dim)
+    _, _, rec = oracle.admm_run([[oracle.translate(raw_train)]], [oracle.translate(raw_test)], conf)
+    prm = driver.AdmmConfig()
+    prm.step_size, prm.global_var, prm.ftrl_alpha, prm.passes, prm.dim = 0.01, 4.0, 0.1, 3, dim
+    wk = driver.Worker(ctx)
+    wk.InitWorker(dim)
+    train = ctx.csr_upload(raw_train.rowptr, raw_train.col, raw_train.val, raw_train.label, dim)
+    test = ctx.csr_upload(raw_test.rowptr, raw_test.col, raw_test.val, raw_test.label, dim)
+    zg, payload = ctx.vec(dim), ctx.vec(dim + driver.RESIDUAL_TAIL)
+    loop = driver.AdmmLoop(wk, driver.Master(ctx), [train], test, prm, zg, payload, lambda buf: ctx.allreduce_sum(buf), 1)
+    for it in range(3):
+        out = loop.iteration(last=it == 2)
+        np.testing.assert_allclose(zg.download(), rec[it]["z"], rtol=1e-5, atol=1e-9)
+        assert out["line"][0] == pytest.approx(rec[it]["lines"][0][0], rel=2e-5)
+        assert out["r2"] == pytest.approx(rec[it]["residuals"][0][0], rel=1e-4, abs=1e-12)
+    last = loop.flush_residuals()
+    assert last["iterations_recorded"] == 3
+    for (r2, s2), r in zip(loop.global_residuals, rec):     # one rank: the sums over ranks are the rank's own
+        assert r2 == pytest.approx(r["residuals"][0][0], rel=1e-4, abs=1e-12)
+        assert s2 == pytest.approx(r["residuals"][0][1], rel=1e-4, abs=1e-14)
+    train.destroy()
+    test.destroy()

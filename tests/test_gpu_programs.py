@@ -189,6 +189,13 @@ def test_three_workers_under_the_local_launcher(tmp_path, oracle):
         x = _read_sparse_sections(tmp_path / "out" / ("admm_weight_" + name))[0]
         np.testing.assert_allclose(x, workers[k].x, rtol=2e-5, atol=1e-6 * max(1.0, np.abs(workers[k].x).max()))
     assert [int(x) for x in re.findall(r"^Finish (\d+)-th iteration$", out, flags=re.M)] == [0, 1, 2]
+    # the residuals over all ranks ride in the tail of the payload, one iteration behind, and the last
+    # pair takes one small exchange of its own: primal = sqrt(sum over ranks |x_r - z|^2), dual = rho |z - z_prev|
+    res = re.findall(r"^\[residual-all\] (\d+) (\S+) (\S+)$", out, flags=re.M)
+    assert [int(a[0]) for a in res] == [0, 1, 2]
+    for (_, pr, du), r in zip(res, rec):
+        assert float(pr) == pytest.approx(np.sqrt(sum(r2 for r2, _ in r["residuals"])), rel=1e-4)
+        assert float(du) == pytest.approx(np.sqrt(r["residuals"][0][1]), rel=1e-4, abs=1e-12)
     # global_metrics = 1: rank 0 also reports logloss and AUC over the test rows of all three ranks
     alls = re.findall(r"^all \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out, flags=re.M)
     assert len(alls) == 3 and all(int(n) == 600 for _, _, n in alls)

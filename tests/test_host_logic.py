@@ -1,4 +1,6 @@
 """Host logic that needs no GPU: the conf grammar, the report line, row sharding."""
+import os
+
 import numpy as np
 
 from admm_amd import dist as adist
@@ -130,3 +132,38 @@ def test_threaded_libsvm_loader_matches_the_oracle_reader(tmp_path, oracle):
     text2 = open(path, "rb").read()
     assert _parsecheck(path, 2, 3, env) == _expected_dump(oracle.parse_libsvm_text(text2, 2, 3))
     assert _parsecheck(path, 1, 3, env) == _expected_dump(oracle.parse_libsvm_text(text2, 1, 3))
+
+
+def test_cpu_side_by_side_job_under_the_launcher(tmp_path, oracle):
+    """the CPU leg that bench.py times beside the GPU: three oracle workers under tools/dmlc_local.py
+    with the shared-memory sum; the consensus vector they end on equals the single-process loop's"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT, make_synth_csr
+    sys.path.insert(0, ROOT)
+    from tools import cpu_admm_worker as caw
+    dim, world, rows_per = 400, 3, 150
+    sample = oracle.translate(make_synth_csr(600, dim, 9, seed=5))
+    nnz = caw.write_shards(sample, str(tmp_path), world, rows_per)
+    assert nnz == int(sample.rowptr[rows_per * world])
+    outs = {}
+    for mode in ("resident", "reparse"):
+        env = dict(os.environ, ADMM_CPU_DUMP=str(tmp_path / ("z_%s.npy" % mode)), OMP_NUM_THREADS="1")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dmlc_local.py"), "-n", str(world),
+                            sys.executable, os.path.join(ROOT, "tools", "cpu_admm_worker.py"), str(tmp_path), str(dim),
+                            mode, "3"], capture_output=True, text=True, timeout=120, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("CPU_ADMM ")][-1][9:])
+        assert rec["iterations"] == 3 and rec["world"] == world and rec["rows"] == rows_per and rec["loop_s"] > 0
+        outs[mode] = np.load(tmp_path / ("z_%s.npy" % mode))
+    np.testing.assert_array_equal(outs["resident"], outs["reparse"])
+    parts = []
+    for k in range(world):
+        b, e = int(sample.rowptr[k * rows_per]), int(sample.rowptr[(k + 1) * rows_per])
+        part = oracle.Csr(sample.rowptr[k * rows_per:(k + 1) * rows_per + 1] - sample.rowptr[k * rows_per],
+                          sample.col[b:e], sample.val[b:e], sample.label[k * rows_per:(k + 1) * rows_per], dim)
+        parts.append([part])
+    conf = oracle.AdmmConf(step_size=0.01, global_var=4.0, ftrl_alpha=0.1, passes=3, dim=dim)
+    _, zg, _ = oracle.admm_run(parts, [p[0] for p in parts], conf)
+    np.testing.assert_allclose(outs["resident"], zg, rtol=1e-6, atol=1e-9)
