@@ -385,10 +385,8 @@ int ensure_taccum(admm_csr *csr) {
   const uint64_t padded = (uint64_t)csr->nblocks * csr->col_block;
   ADMM_HIP_CHECK(hipMalloc(&csr->d_g1, sizeof(long long) * padded));
   ADMM_HIP_CHECK(hipMalloc(&csr->d_g2, sizeof(long long) * padded));
-  ADMM_HIP_CHECK(hipMalloc(&csr->d_mask, sizeof(uint32_t) * (padded / 32 + 1)));
   ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g1, 0, sizeof(long long) * padded, csr->ctx->stream));
   ADMM_HIP_CHECK(hipMemsetAsync(csr->d_g2, 0, sizeof(long long) * padded, csr->ctx->stream));
-  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_mask, 0, sizeof(uint32_t) * (padded / 32 + 1), csr->ctx->stream));
   return ADMM_OK;
 }
 
@@ -406,7 +404,7 @@ static void free_csr(admm_csr *c) {
     hipStreamSynchronize(c->ctx->stream);
   }
   void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_margin, c->d_dmargin, c->d_cache_x, c->d_cache_off, c->d_cache_gl, c->d_tptr,
-                  c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,     c->d_mask,
+                  c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -698,7 +696,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   // drop a previous copy
   for (void **p : {(void **)&csr->d_tptr, (void **)&csr->d_trow, (void **)&csr->d_tcol, (void **)&csr->d_tval,
-                   (void **)&csr->d_g1, (void **)&csr->d_g2, (void **)&csr->d_mask}) {
+                   (void **)&csr->d_g1, (void **)&csr->d_g2}) {
     if (*p) hipFree(*p);
     *p = nullptr;
   }

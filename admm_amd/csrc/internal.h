@@ -128,9 +128,8 @@ struct admm_csr {
   float *d_tval = nullptr;  // nullptr when d_val is
   std::vector<uint64_t> h_tptr;
   // per-coordinate accumulators of the transposed sweep: 64-bit fixed point (value * 2^fx_shift),
-  // so that sums are exact integer adds (order-independent, reproducible) + touched bitmap
+  // so that sums are exact integer adds (order-independent, reproducible)
   long long *d_g1 = nullptr, *d_g2 = nullptr;
-  uint32_t *d_mask = nullptr;
   int fx_shift = 40;
   float vmax = 1.0f;  // max |val| of the set
 };
@@ -170,7 +169,7 @@ struct FwdResult {
 // margins_out when that is given.
 int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w,
                    int nw, float *out_rows, int *nblocks_out, float *margins_out = nullptr);
-// transposed sweep over panels [p0, p1): accumulates into csr->d_g1 (and d_g2 / d_mask in FTRL
+// transposed sweep over panels [p0, p1): accumulates into csr->d_g1 (and d_g2 in FTRL
 // mode), which must be zero on entry
 int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1);
 

@@ -37,7 +37,6 @@ struct FwdArgs {
   const uint64_t *hwarm;  // kWarmWords more mask words per row (columns 64 .. kMaskCols-1)
   const uint32_t *perm;
   unsigned long long *g1, *g2;
-  uint32_t *gmask;
   float scale;
 };
 
@@ -101,8 +100,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   unsigned long long *warm0 = mask0 + kFwSlots * kFwRowSlots;           // [2][kFwRowSlots][kWarmWords] warm masks
   unsigned long long *wacc = warm0 + 2 * kFwRowSlots * kWarmWords;      // [64 * kWarmWords] X^T r of the warm columns
   unsigned long long *wacc2 = wacc + 64 * kWarmWords;                   // [64 * kWarmWords] same for r^2 (FTRL form)
-  unsigned long long *wseen = wacc2 + 64 * kWarmWords;                  // [kWarmWords] warm columns seen (FTRL form)
-  float *prod0 = reinterpret_cast<float *>(wseen + kWarmWords);         // [2][kFwChunk]
+  float *prod0 = reinterpret_cast<float *>(wacc2 + 64 * kWarmWords + kWarmWords);  // [2][kFwChunk]
   float *hot = prod0 + 2 * kFwChunk;                                    // [kFwHot]
   float *tab = hot + kFwHot;                                            // [8][256] byte -> sum of hot weights
   float *lab0 = tab + 8 * 256;                                          // [kFwSlots][kFwRowSlots] labels
@@ -127,7 +125,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   constexpr bool hasval = HASVAL;
   const bool colsums = dense && MODE != FWD_EVAL && MODE != FWD_MARGIN;  // X^T r of the mask columns is wanted
   for (uint32_t j = tid; j < nhot; j += kFwThreads) hot[j] = wsum[j];
-  if (tid < 2 * 64 * kWarmWords + kWarmWords) wacc[tid] = 0ull;  // wacc, wacc2, wseen are contiguous
+  if (tid < 2 * 64 * kWarmWords) wacc[tid] = 0ull;  // wacc, wacc2 are contiguous
   if (dense) {
     // tab[g][byte] = sum of the weights of columns 8g .. 8g+7 selected by the bits of `byte`
     __syncthreads();
@@ -142,7 +140,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   }
   double acc0 = 0, acc1 = 0;
   // per-lane sums of the 64 mask columns over the rows this wave has seen (lane k <-> column k)
-  unsigned long long h1 = 0, h2 = 0, hseen = 0;
+  unsigned long long h1 = 0, h2 = 0;
 
   // Producers keep three register sets of streamed entries, one dword per lane and load: entry
   // j * kFwProducers + ptid of the tile's chunk, so that the 64 entries of one wave-wide load are
@@ -494,7 +492,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
           const float g = p - y;
           out_s[trow] = g;
           my_r = (unsigned long long)(long long)(g * a.scale);
-          my_r2 = (unsigned long long)(long long)(g * g * a.scale);
+          my_r2 = (unsigned long long)(long long)(g * g * a.scale) | 1ull;  // non-zero marks "touched"
           acc0 += (double)g;
           acc1 += (double)(g * g);
         }
@@ -520,7 +518,6 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
           if (MODE == FWD_FTRL) {
             const unsigned long long rv2 = bcast(my_r2, r * kFwLanesPerRow);
             h2 += on ? rv2 : 0ull;
-            hseen |= m;
           }
         }
         // warm columns: few set bits per row, added to per-column LDS accumulators
@@ -533,7 +530,6 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
             atomicAdd(&wacc[c], rrow);
             if (MODE == FWD_FTRL) atomicAdd(&wacc2[c], rrow2);
           }
-          if (MODE == FWD_FTRL && my_w[w]) atomicOr(&wseen[w], my_w[w]);
         }
       }
     }
@@ -554,10 +550,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
     if (tid < 64 * kWarmWords) {
       const uint32_t o = a.perm[64 + tid];
       if (wacc[tid]) atomicAdd(a.g1 + o, wacc[tid]);
-      if (MODE == FWD_FTRL) {
-        if (wacc2[tid]) atomicAdd(a.g2 + o, wacc2[tid]);
-        if ((wseen[tid >> 6] >> (tid & 63)) & 1ull) atomicOr(&a.gmask[o >> 5], 1u << (o & 31));
-      }
+      if (MODE == FWD_FTRL && wacc2[tid]) atomicAdd(a.g2 + o, wacc2[tid]);
     }
     // combine the waves' column sums and add them to the global accumulators
     for (int pass = 0; pass < (MODE == FWD_FTRL ? 2 : 1); ++pass) {
@@ -568,19 +561,6 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
         unsigned long long t = 0;
         for (int w8 = 0; w8 < kFwThreads / 64; ++w8) t += hsum[w8][tid];
         if (t) atomicAdd((pass == 0 ? a.g1 : a.g2) + a.perm[tid], t);
-      }
-    }
-    if (MODE == FWD_FTRL) {
-      __syncthreads();
-      hsum[wave][lane] = hseen;  // wave-uniform
-      __syncthreads();
-      if (tid < 64) {
-        unsigned long long seen = 0;
-        for (int w8 = 0; w8 < kFwThreads / 64; ++w8) seen |= hsum[w8][0];
-        if ((seen >> tid) & 1ull) {
-          const uint32_t o = a.perm[tid];
-          atomicOr(&a.gmask[o >> 5], 1u << (o & 31));
-        }
       }
     }
   }
@@ -625,10 +605,10 @@ __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, cons
 int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
                    float *out_rows, int *nblocks_out, float *margins_out) {
   admm_ctx *ctx = csr->ctx;
-  ADMM_REQUIRE(nw >= 1 && nw <= 4, "forward sweep: 1..4 weight vectors, got %d", nw);
+  ADMM_REQUIRE(nw >= 0 && nw <= 4, "forward sweep: up to 4 weight vectors, got %d", nw);
   ADMM_REQUIRE(r0 <= r1 && r1 <= csr->nrows, "forward sweep: bad row range");
   if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
-  {
+  if (nw > 0) {  // nw == 0: the caller has filled csr->d_wsum itself
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_wsum, dim3(grid_for(csr->dim, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, w[0],
                        nw > 1 ? w[1] : nullptr, nw > 2 ? w[2] : nullptr, nw > 3 ? w[3] : nullptr, csr->d_perm,
@@ -648,7 +628,6 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
       ADMM_REQUIRE(csr->has_t, "forward sweep: the training forms need admm_csr_build_transposed");
       a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
       a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
-      a.gmask = csr->d_mask;
       a.scale = std::ldexp(1.0f, csr->fx_shift);
     }
   }
@@ -716,7 +695,6 @@ struct TArgs {
   const float *tval;
   const float *rvec;  // one float per row
   unsigned long long *g1, *g2;  // 64-bit fixed point, value * scale
-  uint32_t *mask;
   float scale;
   uint32_t nblocks, col_block;
   uint64_t panel0, npanels;  // panels [panel0, panel0 + npanels) are swept by this launch
@@ -731,11 +709,12 @@ __device__ inline fx_t to_fx(float x, float scale) { return (fx_t)(long long)(x 
 // Integer LDS atomics run three times as fast as float ones on gfx950 and make the sum
 // independent of the order of the adds.
 template <bool FTRL>
-__device__ inline void t_accumulate(fx_t *acc, fx_t *acc2, uint32_t *bits, uint32_t c, float x, float v, float scale) {
+__device__ inline void t_accumulate(fx_t *acc, fx_t *acc2, uint32_t c, float x, float v, float scale) {
   if (FTRL) {
+    // the low bit of every squared-gradient addend is set, so a column's sum is non-zero exactly
+    // when some row of the batch stored the column (a gradient can be 0.0f: sigmoid(35) rounds to 1)
     atomicAdd(&acc[c], to_fx(x, scale));
-    atomicAdd(&acc2[c], to_fx(x * x, scale));
-    atomicOr(&bits[c >> 5], 1u << (c & 31));
+    atomicAdd(&acc2[c], to_fx(x * x, scale) | 1ull);
   } else {
     atomicAdd(&acc[c], to_fx(x * v, scale));
   }
@@ -750,39 +729,39 @@ __device__ inline void t_accumulate(fx_t *acc, fx_t *acc2, uint32_t *bits, uint3
 // XCD's L2 (placement affects speed only).
 template <bool FTRL, int kTThreads>
 __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
-  extern __shared__ fx_t acc[];  // [CB] (+ [CB] + [CB/32] bitmap in FTRL mode)
+  extern __shared__ fx_t acc[];  // [CB] (+ [CB] squared-gradient sums in FTRL mode)
+  // eight panels or more: workgroups of one XCD share a panel; fewer (the per-batch launches of the
+  // mini-batch FTRL pass sweep one panel): cells are dealt to the workgroups in order, over all XCDs
+  const bool grouped = a.npanels >= 8;
   const uint64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const uint64_t plocal = (slot / a.nblocks) * 8 + xcd;
+  const uint64_t plocal = grouped ? (slot / a.nblocks) * 8 + xcd : blockIdx.x / a.nblocks;
   if (plocal >= a.npanels) return;
-  const uint32_t blk = (uint32_t)(slot % a.nblocks);
+  const uint32_t blk = (uint32_t)((grouped ? slot : (uint64_t)blockIdx.x) % a.nblocks);
   const uint64_t cell = (a.panel0 + plocal) * a.nblocks + blk;
   const uint64_t beg = a.tptr[cell], end = a.tptr[cell + 1];
   if (beg == end) return;
   const uint32_t CB = a.col_block;
   fx_t *acc2 = acc + CB;
-  uint32_t *bits = reinterpret_cast<uint32_t *>(acc + 2 * CB);
   const float scale = a.scale;
   for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
     acc[c] = 0;
     if (FTRL) acc2[c] = 0;
   }
-  if (FTRL)
-    for (uint32_t c = threadIdx.x; c < CB / 32; c += kTThreads) bits[c] = 0u;
   __syncthreads();
   // head: up to 3 entries before the first 4-aligned index; tail: what is left after the body
   const uint64_t body0 = (beg + 3) & ~3ull;
   const uint64_t body1 = end & ~3ull;
   if (body0 >= body1) {
     for (uint64_t k = beg + threadIdx.x; k < end; k += kTThreads)
-      t_accumulate<FTRL>(acc, acc2, bits, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
+      t_accumulate<FTRL>(acc, acc2, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
   } else {
     if (threadIdx.x < body0 - beg) {
       const uint64_t k = beg + threadIdx.x;
-      t_accumulate<FTRL>(acc, acc2, bits, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
+      t_accumulate<FTRL>(acc, acc2, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
     }
     if (threadIdx.x < end - body1) {
       const uint64_t k = body1 + threadIdx.x;
-      t_accumulate<FTRL>(acc, acc2, bits, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
+      t_accumulate<FTRL>(acc, acc2, a.tcol[k], a.rvec[a.trow[k]], a.tval ? a.tval[k] : 1.0f, scale);
     }
     const bool use_val = !FTRL && a.tval != nullptr;
     uint64_t k = body0 + (uint64_t)threadIdx.x * 4;
@@ -806,14 +785,14 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
         xa0 = a.rvec[ra.x], xa1 = a.rvec[ra.y], xa2 = a.rvec[ra.z], xa3 = a.rvec[ra.w];
         xb0 = a.rvec[rb.x], xb1 = a.rvec[rb.y], xb2 = a.rvec[rb.z], xb3 = a.rvec[rb.w];
       }
-      t_accumulate<FTRL>(acc, acc2, bits, ca.x & 0xFFFFu, xa0, va.x, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, ca.x >> 16, xa1, va.y, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, ca.y & 0xFFFFu, xa2, va.z, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, ca.y >> 16, xa3, va.w, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, cb.x & 0xFFFFu, xb0, vb.x, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, cb.x >> 16, xb1, vb.y, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, cb.y & 0xFFFFu, xb2, vb.z, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, cb.y >> 16, xb3, vb.w, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.x & 0xFFFFu, xa0, va.x, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.x >> 16, xa1, va.y, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.y & 0xFFFFu, xa2, va.z, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.y >> 16, xa3, va.w, scale);
+      t_accumulate<FTRL>(acc, acc2, cb.x & 0xFFFFu, xb0, vb.x, scale);
+      t_accumulate<FTRL>(acc, acc2, cb.x >> 16, xb1, vb.y, scale);
+      t_accumulate<FTRL>(acc, acc2, cb.y & 0xFFFFu, xb2, vb.z, scale);
+      t_accumulate<FTRL>(acc, acc2, cb.y >> 16, xb3, vb.w, scale);
     }
     for (; k < body1; k += 4 * kTThreads) {
       const u32x4 ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.trow + k));
@@ -821,10 +800,10 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
       f32x4 va = {1.f, 1.f, 1.f, 1.f};
       if (use_val) va = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.tval + k));
       const float xa0 = a.rvec[ra.x], xa1 = a.rvec[ra.y], xa2 = a.rvec[ra.z], xa3 = a.rvec[ra.w];
-      t_accumulate<FTRL>(acc, acc2, bits, ca.x & 0xFFFFu, xa0, va.x, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, ca.x >> 16, xa1, va.y, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, ca.y & 0xFFFFu, xa2, va.z, scale);
-      t_accumulate<FTRL>(acc, acc2, bits, ca.y >> 16, xa3, va.w, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.x & 0xFFFFu, xa0, va.x, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.x >> 16, xa1, va.y, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.y & 0xFFFFu, xa2, va.z, scale);
+      t_accumulate<FTRL>(acc, acc2, ca.y >> 16, xa3, va.w, scale);
     }
   }
   __syncthreads();
@@ -832,18 +811,15 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
   for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
     const fx_t s = acc[c];
     if (FTRL) {
-      const uint32_t touched = (bits[c >> 5] >> (c & 31)) & 1u;
-      if (touched) {
+      const fx_t s2 = acc2[c];
+      if (s2 != 0) {
         atomicAdd(&a.g1[gbase + c], s);
-        atomicAdd(&a.g2[gbase + c], acc2[c]);
+        atomicAdd(&a.g2[gbase + c], s2);
       }
     } else if (s != 0) {
       atomicAdd(&a.g1[gbase + c], s);
     }
   }
-  if (FTRL)
-    for (uint32_t c = threadIdx.x; c < CB / 32; c += kTThreads)
-      if (bits[c]) atomicOr(&a.mask[gbase / 32 + c], bits[c]);
 }
 
 int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
@@ -859,14 +835,12 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
   a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
   a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
   a.scale = std::ldexp(1.0f, csr->fx_shift);
-  a.mask = csr->d_mask;
   a.nblocks = csr->nblocks;
   a.col_block = csr->col_block;
   // measurement aid: a gather-free run moves a known number of bytes, which calibrates the
   // hardware counters; it computes nothing useful
   a.no_gather = getenv("ADMM_CALIBRATE_NO_GATHER") != nullptr;
-  const size_t lds = ftrl_mode ? sizeof(fx_t) * 2 * csr->col_block + sizeof(uint32_t) * (csr->col_block / 32)
-                               : sizeof(fx_t) * csr->col_block;
+  const size_t lds = sizeof(fx_t) * csr->col_block * (ftrl_mode ? 2 : 1);
   // more than half of the CU's LDS: one workgroup per CU, so give it the full 1024 threads
   const bool big = lds > 72 * 1024;
   static bool raised[64] = {};  // per device
@@ -886,7 +860,7 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
     a.panel0 = q0;
     a.npanels = std::min<uint64_t>(max_panels, p1 - q0);
     const uint64_t groups = (a.npanels + 7) / 8;
-    const uint32_t grid = (uint32_t)(groups * 8 * csr->nblocks);
+    const uint32_t grid = (uint32_t)((a.npanels >= 8 ? groups * 8 : a.npanels) * csr->nblocks);
     if (ftrl_mode && big)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<true, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, a);
     else if (ftrl_mode)
@@ -1148,48 +1122,57 @@ __device__ inline float ftrl_weight(float z, float n, float c, float alpha, floa
   return (float)((double)num / den);
 }
 
-__global__ void __launch_bounds__(256) k_ftrl_wcur(const float *__restrict__ z, const float *__restrict__ n,
-                                                   const float *__restrict__ c, float alpha, float beta, float l1,
-                                                   float l2, float *__restrict__ wcur, uint64_t dim) {
+// The vector the forward sweep of a batch gathers: lazy weight at the batch's start plus offset, in
+// the sample set's stored column order.  The state is read in its own order (coalesced) and the
+// result goes to the column's stored position (inv: caller's id -> stored id; nullptr: identity).
+__global__ void __launch_bounds__(256) k_ftrl_wsum(const float *__restrict__ z, const float *__restrict__ n,
+                                                   const float *__restrict__ c, const float *__restrict__ offset,
+                                                   const uint32_t *__restrict__ inv, float alpha, float beta, float l1,
+                                                   float l2, float *__restrict__ wsum, uint64_t dim) {
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride)
-    wcur[i] = ftrl_weight(z[i], n[i], c[i], alpha, beta, l1, l2);
+    wsum[inv ? inv[i] : i] = ftrl_weight(z[i], n[i], c[i], alpha, beta, l1, l2) + offset[i];
 }
 
-// per coordinate touched in the batch: w <- wcur (lazy weight), n' = n + G2,
-// z += G1 - wcur (sqrt(n') - sqrt(n)) / alpha ; accumulators and bitmap are cleared
+// per coordinate touched in the batch (its squared-gradient sum is non-zero): w <- the lazy weight at
+// the batch's start (recomputed here: same inputs, same arithmetic as in k_ftrl_wsum), n' = n + G2,
+// z += G1 - w (sqrt(n') - sqrt(n)) / alpha ; the accumulators are cleared
 __global__ void __launch_bounds__(256) k_ftrl_apply(long long *__restrict__ g1, long long *__restrict__ g2,
-                                                    double inv_scale, uint32_t *__restrict__ mask, const float *__restrict__ wcur,
+                                                    double inv_scale, const float *__restrict__ c,
                                                     float *__restrict__ w, float *__restrict__ z,
-                                                    float *__restrict__ n, float alpha,
-                                                    const double *__restrict__ scalars, int bias_rows,
+                                                    float *__restrict__ n, float alpha, float beta, float l1, float l2,
+                                                    const double *__restrict__ partials, int bias_blocks,
                                                     uint64_t dim) {
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
-    bool touched = (mask[i >> 5] >> (i & 31)) & 1u;
-    double G1 = (double)g1[i] * inv_scale, G2 = (double)g2[i] * inv_scale;
-    if (bias_rows && i == 0) {
+    const long long q2 = g2[i];
+    bool touched = q2 != 0;
+    double G1 = 0, G2 = 0;
+    if (touched) {
+      G1 = (double)g1[i] * inv_scale;
+      G2 = (double)q2 * inv_scale;
+    }
+    if (bias_blocks && i == 0) {
+      // a set whose bias column is not held by row masks: the forward sweep left the column's sums as
+      // per-workgroup partials (rows 0 and 1), added here in a fixed order
       touched = true;
-      G1 += scalars[0];
-      G2 += scalars[1];
+      for (int b = 0; b < bias_blocks; ++b) {
+        G1 += partials[0 * kMaxPartialBlocks + b];
+        G2 += partials[1 * kMaxPartialBlocks + b];
+      }
     }
     if (touched) {
-      const float wc = wcur[i];
-      const float nold = n[i];
+      const float nold = n[i], zold = z[i];
+      const float wc = ftrl_weight(zold, nold, c[i], alpha, beta, l1, l2);
       const float nnew = (float)((double)nold + G2);
       const double sigma = (sqrt((double)nnew) - sqrt((double)nold)) / (double)alpha;
       w[i] = wc;
-      z[i] = (float)((double)z[i] + (G1 - sigma * (double)wc));
+      z[i] = (float)((double)zold + (G1 - sigma * (double)wc));
       n[i] = nnew;
       g1[i] = 0;
       g2[i] = 0;
     }
   }
-}
-
-__global__ void __launch_bounds__(256) k_clear_mask(uint32_t *mask, uint64_t words) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) mask[i] = 0u;
 }
 
 // the trailing Predict of FtrlSolver::Run on the last row (src/ftrl.cc:140-141): refresh the
@@ -1216,40 +1199,25 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
                "admm_ftrl_pass: batch (%llu) must equal the transposed copy's panel_rows (%llu)",
                (unsigned long long)batch, (unsigned long long)csr->panel_rows);
   ADMM_TRY(ensure_rowbuf(csr));
-  // the per-coordinate weight snapshot lives in the second half of the L-BFGS workspace slot
-  if (ctx->lbfgs_ws_floats < csr->dim) {
-    if (ctx->lbfgs_ws) {
-      ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      ADMM_HIP_CHECK(hipFree(ctx->lbfgs_ws));
-      ctx->lbfgs_ws = nullptr;
-      ctx->lbfgs_ws_floats = 0;
-    }
-    ADMM_HIP_CHECK(hipMalloc(&ctx->lbfgs_ws, sizeof(float) * csr->dim));
-    ctx->lbfgs_ws_floats = csr->dim;
-  }
-  float *wcur = ctx->lbfgs_ws;
+  if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
   const int egrid = grid_for(csr->dim, 256, ctx->cu_count * 8);
+  const bool bias_partials = csr->has_bias && !csr->hot_dense;
   for (uint64_t p = 0; p < csr->npanels; ++p) {
     const uint64_t r0 = p * csr->panel_rows, r1 = std::min(csr->nrows, r0 + csr->panel_rows);
     {
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
-      hipLaunchKernelGGL(k_ftrl_wcur, dim3(egrid), dim3(256), 0, ctx->stream, z, n, reg_offset, alpha, beta, l1,
-                         l2, wcur, csr->dim);
+      hipLaunchKernelGGL(k_ftrl_wsum, dim3(egrid), dim3(256), 0, ctx->stream, z, n, reg_offset, offset, csr->d_inv,
+                         alpha, beta, l1, l2, csr->d_wsum, csr->dim);
       ADMM_HIP_CHECK(hipGetLastError());
     }
-    const float *wv[2] = {wcur, offset};
     int nblk = 0;
-    ADMM_TRY(launch_forward(csr, FWD_FTRL, r0, r1, wv, 2, csr->d_rowbuf, &nblk));
-    ADMM_TRY(reduce_rows(ctx, 0, 2, nblk));
+    ADMM_TRY(launch_forward(csr, FWD_FTRL, r0, r1, nullptr, 0, csr->d_rowbuf, &nblk));
     ADMM_TRY(launch_transposed(csr, true, p, p + 1));
     {
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
       hipLaunchKernelGGL(k_ftrl_apply, dim3(egrid), dim3(256), 0, ctx->stream, csr->d_g1, csr->d_g2,
-                         std::ldexp(1.0, -csr->fx_shift), csr->d_mask, wcur, w, z, n, alpha, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, csr->dim);
-      ADMM_HIP_CHECK(hipGetLastError());
-      const uint64_t words = ((uint64_t)csr->nblocks * csr->col_block) / 32 + 1;
-      hipLaunchKernelGGL(k_clear_mask, dim3(grid_for(words, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream,
-                         csr->d_mask, words);
+                         std::ldexp(1.0, -csr->fx_shift), reg_offset, w, z, n, alpha, beta, l1, l2, ctx->d_partials,
+                         bias_partials ? nblk : 0, csr->dim);
       ADMM_HIP_CHECK(hipGetLastError());
     }
   }
