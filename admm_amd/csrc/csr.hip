@@ -374,6 +374,262 @@ __global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ ro
   }
 }
 
+// ---- row-panel copy for the forward sweep -----------------------------------------------------
+//
+// One workgroup per panel: a counting sort of the panel's entries by column bin in LDS (count,
+// exclusive scan, scatter).  Rows store their columns in increasing order, so the result is the
+// panel in column order up to the width of a bin: 64 consecutive entries then gather their weights
+// from a few adjacent cache lines instead of 64 scattered ones.
+
+constexpr int kFpBuildThreads = 1024;
+constexpr uint32_t kFpMaxBins = 16384;
+
+struct FpBuildArgs {
+  const uint64_t *xptr;   // row pointers of the source form (compact or plain CSR)
+  const uint32_t *col;    // its column ids
+  const float *val;       // nullptr = implicit 1
+  uint64_t nrows;
+  uint32_t panel_rows, bin_shift, nbins;
+  int skip_bias;          // leave out column 0
+  uint32_t split_bin;     // first bin whose columns are not cached in LDS by the sweep
+  uint32_t *split;        // per panel: offset of that bin's first entry inside the panel
+  uint32_t *fcol;
+  uint16_t *frow;
+  float *fval;
+};
+
+__global__ void __launch_bounds__(kFpBuildThreads) k_fpbuild(FpBuildArgs a) {
+  extern __shared__ uint32_t fp_sh[];  // [nbins] counts / cursors, [kFpBuildThreads] scan scratch
+  uint32_t *cnt = fp_sh;
+  uint32_t *scan = fp_sh + a.nbins;
+  const uint64_t npanels = (a.nrows + a.panel_rows - 1) / a.panel_rows;
+  const int tid = threadIdx.x;
+  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+    const uint64_t r0 = p * a.panel_rows;
+    const uint64_t r1 = r0 + a.panel_rows < a.nrows ? r0 + a.panel_rows : a.nrows;
+    const uint64_t kb = a.xptr[r0], ke = a.xptr[r1];
+    const uint64_t out0 = kb - (a.skip_bias ? r0 : 0);
+    for (uint32_t i = tid; i < a.nbins; i += kFpBuildThreads) cnt[i] = 0;
+    __syncthreads();
+    for (uint64_t k = kb + tid; k < ke; k += kFpBuildThreads) {
+      const uint32_t c = a.col[k];
+      if (a.skip_bias && c == 0) continue;
+      atomicAdd(&cnt[c >> a.bin_shift], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0 .. nbins): every thread owns nbins / threads consecutive bins
+    const uint32_t per = (a.nbins + kFpBuildThreads - 1) / kFpBuildThreads;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t i = tid * per + j;
+      if (i < a.nbins) mine += cnt[i];
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < kFpBuildThreads; off <<= 1) {
+      const uint32_t add = tid >= off ? scan[tid - off] : 0u;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    uint32_t run = scan[tid] - mine;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t i = tid * per + j;
+      if (i < a.nbins) {
+        const uint32_t c = cnt[i];
+        cnt[i] = run;  // becomes the bin's cursor
+        run += c;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) a.split[p] = a.split_bin < a.nbins ? cnt[a.split_bin] : (uint32_t)(ke - kb - (a.skip_bias ? r1 - r0 : 0));
+    __syncthreads();
+    // scatter: a 16-lane group walks a row, so that a row's entries keep their order inside a bin
+    // as far as the atomics allow (any order inside a bin is valid)
+    const int sub = tid & 15, grp = tid >> 4;
+    for (uint64_t r = r0 + grp; r < r1; r += kFpBuildThreads / 16) {
+      const uint64_t b = a.xptr[r], e = a.xptr[r + 1];
+      for (uint64_t k = b + sub; k < e; k += 16) {
+        const uint32_t c = a.col[k];
+        if (a.skip_bias && c == 0) continue;
+        const uint64_t pos = out0 + atomicAdd(&cnt[c >> a.bin_shift], 1u);
+        a.fcol[pos] = c;
+        a.frow[pos] = (uint16_t)(r - r0);
+        if (a.fval) a.fval[pos] = a.val[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Second pass over the row-panel copy: inside every bin, order the entries by column.  Adjacent
+// lanes of the forward sweep then gather from the same or the next cache line (the address unit
+// takes a wave-wide gather four lanes at a time and pays per distinct line among the four).
+// One workgroup per panel: it recounts the bins from the copy itself, then every wave takes bins in
+// turn, one entry per lane, ranks them by all-pairs comparison and stores them back in order (all
+// loads of a wave-instruction have landed before any lane's store issues: in place is safe).  Bins
+// of more than 64 entries keep their order: any order inside a bin is valid.
+__global__ void __launch_bounds__(kFpBuildThreads) k_fpsort(FpBuildArgs a) {
+  extern __shared__ uint32_t fp_sh[];
+  uint32_t *cnt = fp_sh;               // [nbins] counts, then bin starts
+  uint32_t *scan = fp_sh + a.nbins;
+  const uint64_t npanels = (a.nrows + a.panel_rows - 1) / a.panel_rows;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+    const uint64_t r0 = p * a.panel_rows;
+    const uint64_t r1 = r0 + a.panel_rows < a.nrows ? r0 + a.panel_rows : a.nrows;
+    const uint64_t out0 = a.xptr[r0] - (a.skip_bias ? r0 : 0), out1 = a.xptr[r1] - (a.skip_bias ? r1 : 0);
+    for (uint32_t i = tid; i < a.nbins; i += kFpBuildThreads) cnt[i] = 0;
+    __syncthreads();
+    for (uint64_t k = out0 + tid; k < out1; k += kFpBuildThreads) atomicAdd(&cnt[a.fcol[k] >> a.bin_shift], 1u);
+    __syncthreads();
+    const uint32_t per = (a.nbins + kFpBuildThreads - 1) / kFpBuildThreads;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t i = tid * per + j;
+      if (i < a.nbins) mine += cnt[i];
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < kFpBuildThreads; off <<= 1) {
+      const uint32_t add = tid >= off ? scan[tid - off] : 0u;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    uint32_t run = scan[tid] - mine;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t i = tid * per + j;
+      if (i < a.nbins) {
+        const uint32_t c = cnt[i];
+        cnt[i] = run;  // the bin's start
+        run += c;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = (uint32_t)(out1 - out0);
+    for (uint32_t b = wave; b < a.nbins; b += kFpBuildThreads / 64) {
+      const uint32_t s = cnt[b], e = b + 1 < a.nbins ? cnt[b + 1] : total;
+      const uint32_t n = e - s;
+      if (n < 2 || n > 64) continue;  // wave-uniform
+      const bool on = (uint32_t)lane < n;
+      const uint64_t at = out0 + s + (on ? lane : 0);
+      const uint32_t c = on ? a.fcol[at] : 0xFFFFFFFFu;
+      const uint32_t q = a.frow[at];
+      const float v = a.fval ? a.fval[at] : 0.0f;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)j);
+        rank += (cj < c || (cj == c && j < (uint32_t)lane)) ? 1u : 0u;
+      }
+      if (on) {
+        a.fcol[out0 + s + rank] = c;
+        a.frow[out0 + s + rank] = (uint16_t)q;
+        if (a.fval) a.fval[out0 + s + rank] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_maxrowlen(const uint64_t *__restrict__ rowptr, uint64_t nrows,
+                                                   double *__restrict__ partials) {
+  __shared__ unsigned long long sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  unsigned long long m = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < nrows; r += stride) {
+    const unsigned long long len = rowptr[r + 1] - rowptr[r];
+    m = len > m ? len : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_down(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long r = sh[0];
+    for (int i = 1; i < 4; ++i) r = sh[i] > r ? sh[i] : r;
+    partials[blockIdx.x] = (double)r;
+  }
+}
+
+int build_forward_panels(admm_csr *csr) {
+  admm_ctx *ctx = csr->ctx;
+  for (void **p : {(void **)&csr->d_fcol, (void **)&csr->d_frow, (void **)&csr->d_fval, (void **)&csr->d_fsplit}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  csr->has_fp = false;
+  if (csr->nrows == 0 || csr->nnz == 0) return ADMM_OK;
+  {
+    const char *env = getenv("ADMM_FORWARD_PANELS");  // 0: keep the row-major forward sweep everywhere
+    if (env && env[0] == '0') return ADMM_OK;
+  }
+  const uint32_t R = 4096;
+  const bool skip_bias = csr->has_bias && !csr->hot_dense;
+  const uint64_t total = csr->hot_dense ? csr->cnnz : (skip_bias ? csr->nnz - csr->nrows : csr->nnz);
+  // longest stored row (mask-held entries included): bounds a margin's magnitude
+  {
+    const int g = grid_for(csr->nrows, 256, ctx->cu_count * 8);
+    hipLaunchKernelGGL(k_maxrowlen, dim3(g), dim3(256), 0, ctx->stream, csr->d_rowptr, csr->nrows, ctx->d_partials);
+    ADMM_HIP_CHECK(hipGetLastError());
+    std::vector<double> hp(g);
+    ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), ctx->d_partials, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+    ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double m = 1;
+    for (double v : hp) m = std::max(m, v);
+    csr->max_row_len = std::max<uint64_t>(csr->max_row_len, (uint64_t)m);
+    csr->fp_lenbits = 0;
+    while (std::ldexp(1.0, csr->fp_lenbits) < m + 1.0) ++csr->fp_lenbits;
+  }
+  uint32_t bin_shift = 0;
+  while (((csr->dim + (1ull << bin_shift) - 1) >> bin_shift) > kFpMaxBins) ++bin_shift;
+  const uint32_t nbins = (uint32_t)((csr->dim + (1ull << bin_shift) - 1) >> bin_shift);
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_fcol, sizeof(uint32_t) * (total + 8)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_frow, sizeof(uint16_t) * (total + 8)));
+  const float *src_val = csr->hot_dense ? csr->d_cval : csr->d_val;
+  if (src_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_fval, sizeof(float) * (total + 8)));
+  if (!csr->d_fp_shift) ADMM_HIP_CHECK(hipMalloc(&csr->d_fp_shift, sizeof(int) * 2));
+  FpBuildArgs a{};
+  a.xptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
+  a.col = csr->hot_dense ? csr->d_ccol : csr->d_col;
+  a.val = src_val;
+  a.nrows = csr->nrows;
+  a.panel_rows = R;
+  a.bin_shift = bin_shift;
+  a.nbins = nbins;
+  a.split_bin = (kFpHot + (1u << bin_shift) - 1) >> bin_shift;
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_fsplit, sizeof(uint32_t) * ((csr->nrows + R - 1) / R + 1)));
+  a.split = csr->d_fsplit;
+  a.skip_bias = skip_bias ? 1 : 0;
+  a.fcol = csr->d_fcol;
+  a.frow = csr->d_frow;
+  a.fval = csr->d_fval;
+  const size_t lds = sizeof(uint32_t) * (nbins + kFpBuildThreads);
+  static bool raised[64] = {};
+  if (!raised[ctx->device & 63]) {
+    for (const void *fn : {reinterpret_cast<const void *>(&k_fpbuild), reinterpret_cast<const void *>(&k_fpsort)})
+      ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(sizeof(uint32_t) * (kFpMaxBins + kFpBuildThreads))));
+    raised[ctx->device & 63] = true;
+  }
+  const uint64_t npanels = (csr->nrows + R - 1) / R;
+  const int grid = (int)std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 4);
+  hipLaunchKernelGGL(k_fpbuild, dim3(grid), dim3(kFpBuildThreads), lds, ctx->stream, a);
+  ADMM_HIP_CHECK(hipGetLastError());
+  if (bin_shift > 0) {  // bins of one column are in order already
+    hipLaunchKernelGGL(k_fpsort, dim3(grid), dim3(kFpBuildThreads), lds, ctx->stream, a);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  csr->fp_rows = R;
+  csr->fp_bin_cols = 1u << bin_shift;
+  csr->fp_nnz = total;
+  csr->has_fp = true;
+  return ADMM_OK;
+}
+
 int ensure_rowbuf(admm_csr *csr) {
   if (csr->d_rowbuf || csr->nrows == 0) return ADMM_OK;
   ADMM_HIP_CHECK(hipMalloc(&csr->d_rowbuf, sizeof(float) * csr->nrows));
@@ -405,7 +661,8 @@ static void free_csr(admm_csr *c) {
   }
   void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_margin, c->d_dmargin, c->d_cache_x, c->d_cache_off, c->d_cache_gl, c->d_tptr,
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,
-                  c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol};
+                  c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol,
+                  c->d_fcol,   c->d_frow, c->d_fval, c->d_fp_shift, c->d_fsplit};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;
@@ -542,8 +799,11 @@ extern "C" int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]) {
   ADMM_REQUIRE(csr && out, "admm_csr_layout_bytes: NULL argument");
   const uint64_t n = csr->nrows;
   out[0] = 8 * (n + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * n;
-  out[1] = csr->hot_dense ? 8 * (n + 1) + 8 * n * (1 + kWarmWords) + 4 * csr->cnnz + (csr->d_cval ? 4 * csr->cnnz : 0) + 4 * n
-                          : out[0];
+  if (csr->has_fp)  // row-panel copy: masks + (column u32, row u16 [, value]) per remaining entry + labels
+    out[1] = (csr->hot_dense ? 8 * n * (1 + kWarmWords) : 0) + 6 * csr->fp_nnz + (csr->d_fval ? 4 * csr->fp_nnz : 0) + 4 * n;
+  else
+    out[1] = csr->hot_dense ? 8 * (n + 1) + 8 * n * (1 + kWarmWords) + 4 * csr->cnnz + (csr->d_cval ? 4 * csr->cnnz : 0) + 4 * n
+                            : out[0];
   out[2] = csr->has_t ? 8 * (csr->npanels * csr->nblocks + 1) + 6 * csr->tnnz + (csr->d_tval ? 4 * csr->tnnz : 0) : 0;
   out[3] = (csr->d_rowbuf ? 4 * n : 0) + (csr->d_margin ? 4 * n : 0) + (csr->d_dmargin ? 4 * n : 0);
   return ADMM_OK;
@@ -787,6 +1047,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   csr->fx_shift = std::max(8, std::min(40, 61 - need - vbits));
   csr->has_t = true;
   ADMM_TRY(ensure_taccum(csr));
+  ADMM_TRY(build_forward_panels(csr));
   return ADMM_OK;
 }
 

@@ -46,6 +46,10 @@ void set_error(const char *fmt, ...);
 constexpr int kWarmWords = 3;
 constexpr uint32_t kMaskCols = 64u * (1 + kWarmWords);
 
+// leading entries of the gathered vector that the row-panel forward sweep keeps in LDS (a multiple
+// of every bin width the copy's builder can choose)
+constexpr uint32_t kFpHot = 8192;
+
 constexpr int kMaxPartialBlocks = 4096;  // reduction partial slots per output scalar
 constexpr int kPartialScalars = 8;       // scalars a reducing kernel may emit
 
@@ -127,6 +131,21 @@ struct admm_csr {
   uint16_t *d_tcol = nullptr;
   float *d_tval = nullptr;  // nullptr when d_val is
   std::vector<uint64_t> h_tptr;
+  // Row-panel copy read by the forward sweep of a whole set: rows cut into panels of fp_rows rows, a
+  // panel's entries (those not held by the row masks; the bias column of a set without masks is
+  // left out) stored contiguously in the order of their stored column ids (frequency ranks in a
+  // relabelled set), as (stored column id u32, row inside the panel u16 [, value f32]).
+  // d_fsplit[p] = how many of panel p's entries have a column id below kFpHot (they come first).  Panel p starts at
+  // X[min(p fp_rows, nrows)] - (bias left out ? that row index : 0) with X = crowptr or rowptr.
+  bool has_fp = false;
+  uint32_t fp_rows = 0, fp_bin_cols = 0;
+  uint32_t *d_fcol = nullptr;
+  uint16_t *d_frow = nullptr;
+  float *d_fval = nullptr;
+  uint32_t *d_fsplit = nullptr;
+  uint64_t fp_nnz = 0;
+  int fp_lenbits = 0;         // ceil(log2(longest stored row + 1))
+  int *d_fp_shift = nullptr;  // fixed-point shift of the margins, chosen on the device per sweep
   // per-coordinate accumulators of the transposed sweep: 64-bit fixed point (value * 2^fx_shift),
   // so that sums are exact integer adds (order-independent, reproducible)
   long long *d_g1 = nullptr, *d_g2 = nullptr;
@@ -155,6 +174,7 @@ struct KernelTimer {
 int finish_partials(admm_ctx *ctx, int nscalars, int nblocks);
 
 int ensure_rowbuf(admm_csr *csr);
+int build_forward_panels(admm_csr *csr);  // csr.hip
 int ensure_taccum(admm_csr *csr);
 
 // sweeps (sweep.hip)

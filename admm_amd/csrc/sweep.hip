@@ -586,6 +586,302 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// forward sweep over the row-panel copy
+// ---------------------------------------------------------------------------------------------
+//
+// The row-major sweep above gathers one weight per stored entry from a vector of `dim` floats in
+// row order: 64 lanes, 64 different cache lines.  This form turns the access around: a workgroup
+// owns a panel of fp_rows rows and keeps their margins in LDS as 64-bit fixed point; the panel's
+// entries are stored in column order (up to a bin's width), so 64 consecutive entries gather their
+// weights from a few adjacent lines, and the scattered access -- one add per entry to the margin
+// of the entry's row -- goes to LDS, where an integer atomic costs one lane-clock.  Integer adds
+// commute: the margins do not depend on the order of the entries, and a sweep is bit-reproducible.
+// The fixed-point shift is chosen per sweep on the device from max |w| (k_wsum_absmax, k_fp_shift),
+// the largest |value| and the longest row, so that no row sum can leave 62 bits.
+//
+// Entries in the most frequent kMaskCols columns of a relabelled set are not in the copy: they are
+// bits of the row's mask words, summed when the panel's margins are initialised, and their part of
+// X^T r is accumulated in the epilogue (as in the row-major sweep).
+
+constexpr int kRpThreads = 512;
+
+__device__ inline unsigned long long rp_to_fx(float x, float scale) { return (unsigned long long)(long long)(x * scale); }
+
+struct RpArgs {
+  const uint32_t *fcol;
+  const uint16_t *frow;
+  const float *fval;
+  const uint64_t *xptr;    // crowptr (relabelled set) or rowptr: panel p starts at xptr[p R] - (skip_bias ? p R : 0)
+  int skip_bias;
+  const float *label;
+  const uint64_t *hmask, *hwarm;  // nullptr: no mask tier
+  const uint32_t *perm;    // stored id -> caller's id (relabelled sets), for the column sums' destination
+  const uint32_t *split;   // per panel: entries whose column is below nhot (they come first)
+  uint32_t nhot;           // leading entries of w cached in LDS
+  const float *w;          // gathered vector in the set's stored column order
+  const int *shift;        // fixed-point shift of this sweep
+  uint64_t nrows;
+  uint32_t panel_rows;
+  int add_bias;            // no mask tier, bias column left out of the copy: every margin starts at w[0]
+  float *out, *out2;
+  double *partials;
+  unsigned long long *g1;  // X^T r of the mask columns goes here (fixed point, gscale), nullptr: not wanted
+  float gscale;
+};
+
+template <int MODE, bool HASVAL>
+__global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
+  extern __shared__ unsigned long long rp_acc[];                     // [panel_rows] margins, fixed point; then float hot[nhot]
+  float *hot = reinterpret_cast<float *>(rp_acc + a.panel_rows);     // leading entries of w (the mask columns first)
+  __shared__ float tab[8 * 256];                                     // byte of the first mask word -> sum of its weights
+  __shared__ unsigned long long wacc[kMaskCols];                     // X^T r of the mask columns, this workgroup
+  __shared__ double shred[kRpThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool dense = a.hmask != nullptr;
+  const bool colsums = dense && MODE == FWD_LBFGS && a.g1 != nullptr;
+  const uint32_t R = a.panel_rows;
+  const uint64_t npanels = (a.nrows + R - 1) / R;
+  const int shift = *a.shift;
+  const float scale = ldexpf(1.0f, shift);
+  const double inv_scale = ldexp(1.0, -shift);
+  for (uint32_t j = tid; j < a.nhot; j += kRpThreads) hot[j] = a.w[j];
+  if (tid < (int)kMaskCols) wacc[tid] = 0ull;
+  __syncthreads();
+  if (dense) {
+    for (int i = tid; i < 8 * 256; i += kRpThreads) {
+      const int g = i >> 8, byte = i & 255;
+      float t = 0.0f;
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit)
+        if (byte & (1 << bit)) t += hot[8 * g + bit];
+      tab[i] = t;
+    }
+  }
+  const float w0 = a.add_bias ? a.w[0] : 0.0f;
+  double acc0 = 0, acc1 = 0;
+  unsigned long long h1 = 0;  // lane k: X^T r of mask column k over the rows this wave has seen
+  auto bcast = [](unsigned long long v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  __syncthreads();
+  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+    const uint64_t r0 = p * R;
+    const uint32_t nr = (uint32_t)(a.nrows - r0 < R ? a.nrows - r0 : R);
+    // ---- margins start at the mask tier's part (or at the bias weight)
+    for (uint32_t r = tid; r < nr; r += kRpThreads) {
+      float m0 = w0;
+      if (dense) {
+        const unsigned long long m = a.hmask[r0 + r];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) m0 += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
+#pragma unroll
+        for (int w = 0; w < kWarmWords; ++w) {
+          unsigned long long mw = a.hwarm[(r0 + r) * kWarmWords + w];
+          while (mw) {
+            m0 += hot[64 * (w + 1) + __builtin_ctzll(mw)];
+            mw &= mw - 1;
+          }
+        }
+      }
+      rp_acc[r] = rp_to_fx(m0, scale);
+    }
+    __syncthreads();
+    // ---- the panel's entries: stream, look up or gather, add.  Entries come in the order of their
+    // column ids: first those whose weight is in the LDS copy, then the rest, whose weights are
+    // gathered from memory -- adjacent lanes from the same or neighbouring cache lines.
+    {
+      const uint64_t rend = r0 + nr;
+      const uint64_t beg = a.xptr[r0] - (a.skip_bias ? r0 : 0), end = a.xptr[rend] - (a.skip_bias ? rend : 0);
+      const uint64_t mid = beg + a.split[p];
+      uint64_t k = beg + tid;
+      for (; k + 3 * kRpThreads < mid; k += 4 * kRpThreads) {
+        const uint32_t c0 = __builtin_nontemporal_load(a.fcol + k), c1 = __builtin_nontemporal_load(a.fcol + k + kRpThreads),
+                       c2 = __builtin_nontemporal_load(a.fcol + k + 2 * kRpThreads),
+                       c3 = __builtin_nontemporal_load(a.fcol + k + 3 * kRpThreads);
+        const uint32_t q0 = __builtin_nontemporal_load(a.frow + k), q1 = __builtin_nontemporal_load(a.frow + k + kRpThreads),
+                       q2 = __builtin_nontemporal_load(a.frow + k + 2 * kRpThreads),
+                       q3 = __builtin_nontemporal_load(a.frow + k + 3 * kRpThreads);
+        float x0 = hot[c0], x1 = hot[c1], x2 = hot[c2], x3 = hot[c3];
+        if (HASVAL) {
+          x0 *= __builtin_nontemporal_load(a.fval + k);
+          x1 *= __builtin_nontemporal_load(a.fval + k + kRpThreads);
+          x2 *= __builtin_nontemporal_load(a.fval + k + 2 * kRpThreads);
+          x3 *= __builtin_nontemporal_load(a.fval + k + 3 * kRpThreads);
+        }
+        atomicAdd(&rp_acc[q0], rp_to_fx(x0, scale));
+        atomicAdd(&rp_acc[q1], rp_to_fx(x1, scale));
+        atomicAdd(&rp_acc[q2], rp_to_fx(x2, scale));
+        atomicAdd(&rp_acc[q3], rp_to_fx(x3, scale));
+      }
+      for (; k < mid; k += kRpThreads) {
+        const float x = hot[a.fcol[k]];
+        atomicAdd(&rp_acc[a.frow[k]], rp_to_fx(HASVAL ? x * a.fval[k] : x, scale));
+      }
+      k = mid + tid;
+      for (; k + 3 * kRpThreads < end; k += 4 * kRpThreads) {
+        const uint32_t c0 = __builtin_nontemporal_load(a.fcol + k), c1 = __builtin_nontemporal_load(a.fcol + k + kRpThreads),
+                       c2 = __builtin_nontemporal_load(a.fcol + k + 2 * kRpThreads),
+                       c3 = __builtin_nontemporal_load(a.fcol + k + 3 * kRpThreads);
+        const uint32_t q0 = __builtin_nontemporal_load(a.frow + k), q1 = __builtin_nontemporal_load(a.frow + k + kRpThreads),
+                       q2 = __builtin_nontemporal_load(a.frow + k + 2 * kRpThreads),
+                       q3 = __builtin_nontemporal_load(a.frow + k + 3 * kRpThreads);
+        float x0 = a.w[c0], x1 = a.w[c1], x2 = a.w[c2], x3 = a.w[c3];
+        if (HASVAL) {
+          x0 *= __builtin_nontemporal_load(a.fval + k);
+          x1 *= __builtin_nontemporal_load(a.fval + k + kRpThreads);
+          x2 *= __builtin_nontemporal_load(a.fval + k + 2 * kRpThreads);
+          x3 *= __builtin_nontemporal_load(a.fval + k + 3 * kRpThreads);
+        }
+        atomicAdd(&rp_acc[q0], rp_to_fx(x0, scale));
+        atomicAdd(&rp_acc[q1], rp_to_fx(x1, scale));
+        atomicAdd(&rp_acc[q2], rp_to_fx(x2, scale));
+        atomicAdd(&rp_acc[q3], rp_to_fx(x3, scale));
+      }
+      for (; k < end; k += kRpThreads) {
+        const float x = a.w[a.fcol[k]];
+        atomicAdd(&rp_acc[a.frow[k]], rp_to_fx(HASVAL ? x * a.fval[k] : x, scale));
+      }
+    }
+    __syncthreads();
+    // ---- per-row epilogue; a wave takes 64 consecutive rows per trip (uniform trip count)
+    for (uint32_t rb = wave * 64; rb < nr; rb += kRpThreads) {
+      const uint32_t r = rb + lane;
+      const bool on = r < nr;
+      unsigned long long rv = 0;
+      if (on) {
+        const float m = (float)((double)(long long)rp_acc[r] * inv_scale);
+        const float lab = a.label[r0 + r];
+        if (MODE == FWD_MARGIN) {
+          a.out[r0 + r] = m;
+        } else if (MODE == FWD_EVAL) {
+          // src/metrics.cc:104-105: double predict, -log p / -log(1-p)
+          const double pd = 1.0f / (1 + exp(-(double)clamp35(m)));
+          a.out[r0 + r] = (float)pd;
+          acc0 += lab > 0 ? -log(pd) : -log(1 - pd);
+        } else {
+          const float t = lab > 0 ? 1.0f : 0.0f;
+          const float loss = log1pf(expf(-fabsf(m))) + (t > 0 ? fmaxf(-m, 0.0f) : fmaxf(m, 0.0f));
+          const float res = 1.0f / (1.0f + expf(-m)) - t;
+          a.out[r0 + r] = res;
+          if (a.out2) a.out2[r0 + r] = m;
+          rv = (unsigned long long)(long long)(res * a.gscale);
+          acc0 += (double)loss;
+          acc1 += (double)res;
+        }
+      }
+      if (colsums) {
+        // X^T r of the mask columns over these 64 rows: the dense word by broadcast + inverse ballot
+        // (lane k <-> column k), the sparse words by walking each row's set bits into LDS accumulators
+        // (the same sums by broadcast and ballot for all four words were slower: 1.90 against 1.64 ms
+        // per 10M rows)
+        const unsigned long long m0 = on ? a.hmask[r0 + r] : 0ull;
+        unsigned long long mw[kWarmWords];
+#pragma unroll
+        for (int w = 0; w < kWarmWords; ++w) mw[w] = on ? a.hwarm[(r0 + r) * kWarmWords + w] : 0ull;
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll 4
+        for (int kk = 0; kk < 64; kk += 4) {
+          p0 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk)) ? bcast(rv, kk) : 0ull;
+          p1 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk + 1)) ? bcast(rv, kk + 1) : 0ull;
+          p2 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk + 2)) ? bcast(rv, kk + 2) : 0ull;
+          p3 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk + 3)) ? bcast(rv, kk + 3) : 0ull;
+        }
+        h1 += (p0 + p1) + (p2 + p3);
+        while (mw[0] | mw[1] | mw[2]) {
+#pragma unroll
+          for (int w = 0; w < kWarmWords; ++w) {
+            if (mw[w]) {
+              atomicAdd(&wacc[64 * (w + 1) + __builtin_ctzll(mw[w])], rv);
+              mw[w] &= mw[w] - 1;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // the margins are reused by the next panel
+  }
+  static_assert(kWarmWords == 3, "the walk above names three words");
+  if (colsums) {
+    if (h1) atomicAdd(&wacc[lane], h1);
+    __syncthreads();
+    if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.g1 + a.perm[tid], wacc[tid]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    acc0 += __shfl_down(acc0, off, 64);
+    acc1 += __shfl_down(acc1, off, 64);
+  }
+  __syncthreads();
+  if (lane == 0) shred[wave] = acc0;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0;
+    for (int w8 = 0; w8 < kRpThreads / 64; ++w8) t += shred[w8];
+    a.partials[0 * kMaxPartialBlocks + blockIdx.x] = t;
+  }
+  __syncthreads();
+  if (lane == 0) shred[wave] = acc1;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0;
+    for (int w8 = 0; w8 < kRpThreads / 64; ++w8) t += shred[w8];
+    a.partials[1 * kMaxPartialBlocks + blockIdx.x] = t;
+  }
+}
+
+// wsum (see k_wsum), plus the largest |wsum| per workgroup
+__global__ void __launch_bounds__(256) k_wsum_absmax(const float *__restrict__ w0, const float *__restrict__ w1,
+                                                     const float *__restrict__ w2, const float *__restrict__ w3,
+                                                     const uint32_t *__restrict__ perm, float *__restrict__ wsum,
+                                                     uint64_t dim, float *__restrict__ blockmax) {
+  __shared__ float sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  float m = 0.0f;
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < dim; j += stride) {
+    const uint64_t o = perm ? perm[j] : j;
+    float s = w0[o];
+    if (w1) s += w1[o];
+    if (w2) s += w2[o];
+    if (w3) s += w3[o];
+    wsum[j] = s;
+    const float av = fabsf(s);
+    m = av > m ? av : m;  // a NaN weight is not seen here: it reaches the margins through to_fx as garbage
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_down(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// shift = the largest s with (longest row) * max |w v| * 2^s < 2^61, at most 40
+__global__ void __launch_bounds__(256) k_fp_shift(const float *__restrict__ blockmax, int nblocks, float vmax, int lenbits,
+                                                  int *__restrict__ shift_out) {
+  __shared__ float sh[256];
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) m = fmaxf(m, blockmax[i]);
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float top = sh[0] * vmax;
+    int e = 0;
+    if (top > 0.0f && top < 3.0e38f) frexpf(top, &e);  // top < 2^e
+    else if (!(top < 3.0e38f)) e = 128;
+    int s = 61 - lenbits - e;
+    s = s > 40 ? 40 : (s < -60 ? -60 : s);
+    *shift_out = s;
+  }
+}
+
 // wsum[j] = sum over the weight vectors of w_g[perm[j]]  (perm == nullptr: identity)
 __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, const float *__restrict__ w1,
                                               const float *__restrict__ w2, const float *__restrict__ w3,
@@ -602,12 +898,88 @@ __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, cons
   }
 }
 
+// whole-set sweep over the row-panel copy
+static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const *w, int nw, float *out_rows,
+                                 int *nblocks_out, float *margins_out) {
+  admm_ctx *ctx = csr->ctx;
+  const int wgrid = grid_for(csr->dim, 256, std::min(ctx->cu_count * 8, kMaxPartialBlocks));
+  float *blockmax = reinterpret_cast<float *>(ctx->d_partials + 6 * (size_t)kMaxPartialBlocks);
+  {
+    KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_wsum_absmax, dim3(wgrid), dim3(256), 0, ctx->stream, w[0], nw > 1 ? w[1] : nullptr,
+                       nw > 2 ? w[2] : nullptr, nw > 3 ? w[3] : nullptr, csr->d_perm, csr->d_wsum, csr->dim, blockmax);
+    ADMM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_fp_shift, dim3(1), dim3(256), 0, ctx->stream, blockmax, wgrid, csr->vmax, csr->fp_lenbits,
+                       csr->d_fp_shift);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  RpArgs a{};
+  a.fcol = csr->d_fcol;
+  a.frow = csr->d_frow;
+  a.fval = csr->d_fval;
+  a.xptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
+  a.skip_bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
+  a.add_bias = a.skip_bias;
+  a.label = csr->d_label;
+  if (csr->hot_dense) {
+    a.hmask = csr->d_hmask;
+    a.hwarm = csr->d_hwarm;
+    a.perm = csr->d_perm;
+  }
+  a.w = csr->d_wsum;
+  a.split = csr->d_fsplit;
+  a.nhot = (uint32_t)std::min<uint64_t>(kFpHot, csr->dim);
+  a.shift = csr->d_fp_shift;
+  a.nrows = csr->nrows;
+  a.panel_rows = csr->fp_rows;
+  a.out = out_rows;
+  a.out2 = margins_out;
+  a.partials = ctx->d_partials;
+  if (mode == FWD_LBFGS && csr->hot_dense) {
+    ADMM_REQUIRE(csr->has_t, "forward sweep: the training forms need admm_csr_build_transposed");
+    a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
+    a.gscale = std::ldexp(1.0f, csr->fx_shift);
+  }
+  const size_t lds = sizeof(unsigned long long) * csr->fp_rows + sizeof(float) * a.nhot;
+  static bool raised[64] = {};
+  if (!raised[ctx->device & 63]) {
+    for (const void *fn : {reinterpret_cast<const void *>(&k_forward_rp<FWD_EVAL, true>),
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_EVAL, false>),
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_LBFGS, true>),
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_LBFGS, false>),
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_MARGIN, true>),
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_MARGIN, false>)})
+      ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    raised[ctx->device & 63] = true;
+  }
+  const uint64_t npanels = (csr->nrows + csr->fp_rows - 1) / csr->fp_rows;
+  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 2));  // two resident per CU
+  *nblocks_out = grid;
+  const bool hasval = a.fval != nullptr;
+  KernelTimer t(ctx, mode == FWD_EVAL ? ADMM_K_FORWARD_EVAL : ADMM_K_FORWARD);
+#define RP_LAUNCH(M)                                                                                                \
+  if (hasval) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_rp<M, true>), dim3(grid), dim3(kRpThreads), lds, ctx->stream, a); \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_rp<M, false>), dim3(grid), dim3(kRpThreads), lds, ctx->stream, a);
+  if (mode == FWD_EVAL) {
+    RP_LAUNCH(FWD_EVAL)
+  } else if (mode == FWD_LBFGS) {
+    RP_LAUNCH(FWD_LBFGS)
+  } else {
+    RP_LAUNCH(FWD_MARGIN)
+  }
+#undef RP_LAUNCH
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
 int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
                    float *out_rows, int *nblocks_out, float *margins_out) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(nw >= 0 && nw <= 4, "forward sweep: up to 4 weight vectors, got %d", nw);
   ADMM_REQUIRE(r0 <= r1 && r1 <= csr->nrows, "forward sweep: bad row range");
   if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
+  if (csr->has_fp && nw > 0 && mode != FWD_FTRL && r0 == 0 && r1 == csr->nrows)
+    return launch_forward_panels(csr, mode, w, nw, out_rows, nblocks_out, margins_out);
   if (nw > 0) {  // nw == 0: the caller has filled csr->d_wsum itself
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_wsum, dim3(grid_for(csr->dim, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, w[0],
