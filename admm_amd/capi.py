@@ -178,6 +178,7 @@ class Context:
                                       C.byref(h)))
         self.h = h
         self.rank, self.world = 0, 1
+        self.exchange = None
 
     def close(self):
         if self.h:
@@ -274,8 +275,13 @@ class Context:
                                             residuals.ptr if residuals is not None else None))
 
     def allreduce_sum(self, buf, n=None):
-        """rabit::Allreduce<op::Sum> (src/admm_allreduce.cpp:69): in-place float sum over ranks on RCCL"""
-        _check(self.L.admm_allreduce_sum_f32(self.h, buf.ptr, buf.n if n is None else int(n)))
+        """rabit::Allreduce<op::Sum> (src/admm_allreduce.cpp:69): in-place float sum over ranks on RCCL.
+        `exchange` (set by a rehearsal in which several ranks share one GPU, where RCCL cannot run)
+        replaces the library call by a caller-supplied function of (vector, count)."""
+        cnt = buf.n if n is None else int(n)
+        if self.exchange is not None:
+            return self.exchange(buf, cnt)
+        _check(self.L.admm_allreduce_sum_f32(self.h, buf.ptr, cnt))
 
     def comm_unique_id(self):
         """128 bytes that rank 0 hands to every rank (admm_comm_unique_id)"""

@@ -101,8 +101,13 @@ def allreduce_max_(t):
 
 
 def barrier():
+    """all ranks meet; on a group with a gloo half the meeting is a sum of one host float (dist.barrier
+    would pick the device backend and build an RCCL communicator just for that)"""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if "gloo" in str(dist.get_backend()):
+            dist.all_reduce(torch.zeros(1))
+        else:
+            dist.barrier()
 
 
 def finalize():

@@ -201,14 +201,25 @@ class Job:
             raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run" % (args.gpus, self.world))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+        # Rehearsal of the N > 1 code path on a box with ONE GPU (ADMM_BENCH_SHARE_GPU=1): every rank drives
+        # GPU 0 and the payload is summed on the host through gloo, because RCCL cannot place two ranks on one
+        # GPU.  It checks the rank logic, not the collective; its numbers mean nothing.
+        self.share_gpu = os.environ.get("ADMM_BENCH_SHARE_GPU") == "1" and self.world > 1
+        if self.share_gpu:
+            self.local_rank = 0
         torch.cuda.set_device(self.local_rank)
         if self.world > 1:
             # control plane only (barriers, max of the timings, the communicator id): host tensors on gloo;
             # the nccl half is created lazily and only used with --allreduce torch
-            adist.init("cpu:gloo,cuda:nccl")
+            adist.init("gloo" if self.share_gpu else "cpu:gloo,cuda:nccl")
         self.ctx = capi.Context(self.local_rank)
         self.allreduce_path = "single rank"
-        if self.world > 1:
+        if self.share_gpu:
+            self.ctx.rank, self.ctx.world = self.rank, self.world
+            self.ctx.exchange = self._host_exchange
+            self.allreduce_path = "REHEARSAL: host sum through gloo, all ranks on one GPU"
+            args.allreduce = "lib"
+        elif self.world > 1:
             self.allreduce_path = "admm_allreduce_sum_f32 (RCCL through libadmm_hip.so)"
             if args.allreduce == "lib":
                 try:
@@ -228,6 +239,12 @@ class Job:
         """in-place float sum over ranks of a library device vector, on the library's communicator"""
         if self.world > 1:
             self.ctx.allreduce_sum(vec, n)
+
+    def _host_exchange(self, vec, cnt):
+        part = self.capi.DeviceVec.from_ptr(self.ctx, vec.ptr.value, cnt)
+        t = self.torch.from_numpy(part.download())
+        self.adist.allreduce_sum_(t)
+        part.upload(t.numpy())
 
     def host_sum(self, values):
         if self.world == 1:
