@@ -60,6 +60,7 @@ struct TBuildArgs {
   uint32_t col_block, nblocks;
   int skip_bias;
   int hot_dense;  // entries held by the per-row masks (relabelled id < kMaskCols, value 1) are left out
+  uint32_t stream_cols;  // entries whose stored id is below this are in the column stream, not in the cells
   unsigned long long *cell_count;   // pass 1: entries per cell
   unsigned long long *cell_cursor;  // pass 2: next free slot per cell (starts at tptr[cell])
   uint32_t *trow;
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
     const uint64_t kb = a.rowptr[r0], ke = a.rowptr[r1];
     for (uint64_t k = kb + threadIdx.x; k < ke; k += 256) {
       uint32_t c = a.col[k];
+      if (c < a.stream_cols) continue;
       if (a.hot_dense && c < kMaskCols && (!a.val || a.val[k] == 1.0f)) continue;
       if (a.perm) c = a.perm[c];
       if (a.skip_bias && c == 0) continue;
@@ -112,6 +114,7 @@ __global__ void __launch_bounds__(256) k_tbuild(TBuildArgs a) {
         const uint64_t b = a.rowptr[r], e = a.rowptr[r + 1];
         for (uint64_t k = b + sub; k < e; k += 16) {
           uint32_t c = a.col[k];
+          if (c < a.stream_cols) continue;
           if (a.hot_dense && c < kMaskCols && (!a.val || a.val[k] == 1.0f)) continue;
           if (a.perm) c = a.perm[c];
           if (a.skip_bias && c == 0) continue;
@@ -376,10 +379,9 @@ __global__ void __launch_bounds__(256) k_compact(const uint64_t *__restrict__ ro
 
 // ---- row-panel copy for the forward sweep -----------------------------------------------------
 //
-// One workgroup per panel: a counting sort of the panel's entries by column bin in LDS (count,
-// exclusive scan, scatter).  Rows store their columns in increasing order, so the result is the
-// panel in column order up to the width of a bin: 64 consecutive entries then gather their weights
-// from a few adjacent cache lines instead of 64 scattered ones.
+// The entries outside the hot stream.  One workgroup per panel: a counting sort of the panel's
+// entries by column bin in LDS (count, exclusive scan, scatter), so that 64 consecutive entries
+// gather their weights from a few adjacent cache lines instead of 64 scattered ones.
 
 constexpr int kFpBuildThreads = 1024;
 constexpr uint32_t kFpMaxBins = 16384;
@@ -391,8 +393,8 @@ struct FpBuildArgs {
   uint64_t nrows;
   uint32_t panel_rows, bin_shift, nbins;
   int skip_bias;          // leave out column 0
-  uint32_t split_bin;     // first bin whose columns are not cached in LDS by the sweep
-  uint32_t *split;        // per panel: offset of that bin's first entry inside the panel
+  uint32_t nhot;          // ids below this are in the hot stream, not here
+  const uint64_t *fptr;   // per panel: where its entries start in fcol / frow / fval
   uint32_t *fcol;
   uint16_t *frow;
   float *fval;
@@ -408,12 +410,12 @@ __global__ void __launch_bounds__(kFpBuildThreads) k_fpbuild(FpBuildArgs a) {
     const uint64_t r0 = p * a.panel_rows;
     const uint64_t r1 = r0 + a.panel_rows < a.nrows ? r0 + a.panel_rows : a.nrows;
     const uint64_t kb = a.xptr[r0], ke = a.xptr[r1];
-    const uint64_t out0 = kb - (a.skip_bias ? r0 : 0);
+    const uint64_t out0 = a.fptr[p];
     for (uint32_t i = tid; i < a.nbins; i += kFpBuildThreads) cnt[i] = 0;
     __syncthreads();
     for (uint64_t k = kb + tid; k < ke; k += kFpBuildThreads) {
       const uint32_t c = a.col[k];
-      if (a.skip_bias && c == 0) continue;
+      if (c < a.nhot || (a.skip_bias && c == 0)) continue;
       atomicAdd(&cnt[c >> a.bin_shift], 1u);
     }
     __syncthreads();
@@ -442,8 +444,6 @@ __global__ void __launch_bounds__(kFpBuildThreads) k_fpbuild(FpBuildArgs a) {
       }
     }
     __syncthreads();
-    if (tid == 0) a.split[p] = a.split_bin < a.nbins ? cnt[a.split_bin] : (uint32_t)(ke - kb - (a.skip_bias ? r1 - r0 : 0));
-    __syncthreads();
     // scatter: a 16-lane group walks a row, so that a row's entries keep their order inside a bin
     // as far as the atomics allow (any order inside a bin is valid)
     const int sub = tid & 15, grp = tid >> 4;
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(kFpBuildThreads) k_fpbuild(FpBuildArgs a) {
       const uint64_t b = a.xptr[r], e = a.xptr[r + 1];
       for (uint64_t k = b + sub; k < e; k += 16) {
         const uint32_t c = a.col[k];
-        if (a.skip_bias && c == 0) continue;
+        if (c < a.nhot || (a.skip_bias && c == 0)) continue;
         const uint64_t pos = out0 + atomicAdd(&cnt[c >> a.bin_shift], 1u);
         a.fcol[pos] = c;
         a.frow[pos] = (uint16_t)(r - r0);
@@ -476,9 +476,7 @@ __global__ void __launch_bounds__(kFpBuildThreads) k_fpsort(FpBuildArgs a) {
   const uint64_t npanels = (a.nrows + a.panel_rows - 1) / a.panel_rows;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
-    const uint64_t r0 = p * a.panel_rows;
-    const uint64_t r1 = r0 + a.panel_rows < a.nrows ? r0 + a.panel_rows : a.nrows;
-    const uint64_t out0 = a.xptr[r0] - (a.skip_bias ? r0 : 0), out1 = a.xptr[r1] - (a.skip_bias ? r1 : 0);
+    const uint64_t out0 = a.fptr[p], out1 = a.fptr[p + 1];
     for (uint32_t i = tid; i < a.nbins; i += kFpBuildThreads) cnt[i] = 0;
     __syncthreads();
     for (uint64_t k = out0 + tid; k < out1; k += kFpBuildThreads) atomicAdd(&cnt[a.fcol[k] >> a.bin_shift], 1u);
@@ -532,6 +530,341 @@ __global__ void __launch_bounds__(kFpBuildThreads) k_fpsort(FpBuildArgs a) {
   }
 }
 
+// ---- hot stream of the row-panel copy ---------------------------------------------------------
+
+struct HpBuildArgs {
+  const uint64_t *xptr;
+  const uint32_t *col;
+  const float *val;
+  uint64_t nrows;
+  uint32_t panel_rows, nhot;
+  int skip_bias;
+  uint32_t *hlen, *clen;   // count pass: per panel, words of the hot stream / entries outside it
+  const uint64_t *hbase;   // fill pass
+  uint16_t *hcol;
+  float *hval;
+  uint16_t *hfirst;
+};
+
+constexpr int kHpBuildThreads = 1024;
+
+// per panel: how many words its hot stream has (one per entry below nhot, one filler per row
+// without any) and how many entries stay outside it
+__global__ void __launch_bounds__(kHpBuildThreads) k_hpcount(HpBuildArgs a) {
+  __shared__ uint32_t sh[2];
+  const uint64_t npanels = (a.nrows + a.panel_rows - 1) / a.panel_rows;
+  const int tid = threadIdx.x;
+  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+    const uint64_t r0 = p * a.panel_rows;
+    const uint64_t r1 = r0 + a.panel_rows < a.nrows ? r0 + a.panel_rows : a.nrows;
+    if (tid < 2) sh[tid] = 0;
+    __syncthreads();
+    uint32_t hw = 0, cw = 0;
+    for (uint64_t r = r0 + tid; r < r1; r += kHpBuildThreads) {
+      uint32_t h = 0;
+      for (uint64_t k = a.xptr[r], e = a.xptr[r + 1]; k < e; ++k) {
+        const uint32_t c = a.col[k];
+        if (a.skip_bias && c == 0) continue;
+        if (c < a.nhot) ++h;
+        else ++cw;
+      }
+      hw += h ? h : 1u;
+    }
+    atomicAdd(&sh[0], hw);
+    atomicAdd(&sh[1], cw);
+    __syncthreads();
+    if (tid == 0) {
+      a.hlen[p] = sh[0];
+      a.clen[p] = sh[1];
+    }
+    __syncthreads();
+  }
+}
+
+// writes the hot stream of every panel in the lane-interleaved layout, and the row each lane starts in
+__global__ void __launch_bounds__(kHpBuildThreads) k_hpfill(HpBuildArgs a) {
+  extern __shared__ uint32_t hp_sh[];  // [panel_rows + 1] word offsets of the rows, [kHpBuildThreads] scan scratch
+  uint32_t *off = hp_sh;
+  uint32_t *scan = hp_sh + a.panel_rows + 1;
+  const uint64_t npanels = (a.nrows + a.panel_rows - 1) / a.panel_rows;
+  const int tid = threadIdx.x;
+  const uint32_t per = (a.panel_rows + kHpBuildThreads - 1) / kHpBuildThreads;  // consecutive rows per thread
+  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+    const uint64_t r0 = p * a.panel_rows;
+    const uint32_t nr = (uint32_t)(a.nrows - r0 < a.panel_rows ? a.nrows - r0 : a.panel_rows);
+    const uint64_t hb = a.hbase[p];
+    const uint32_t S = (uint32_t)((a.hbase[p + 1] - hb) / kHpLanes);  // words per lane, a multiple of 4
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t r = tid * per + j;
+      if (r < nr) {
+        uint32_t h = 0;
+        for (uint64_t k = a.xptr[r0 + r], e = a.xptr[r0 + r + 1]; k < e; ++k) {
+          const uint32_t c = a.col[k];
+          if (c < a.nhot && !(a.skip_bias && c == 0)) ++h;
+        }
+        h = h ? h : 1u;
+        off[r] = h;
+        mine += h;
+      }
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < kHpBuildThreads; o <<= 1) {
+      const uint32_t add = tid >= o ? scan[tid - o] : 0u;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    const uint32_t total = scan[kHpBuildThreads - 1];
+    uint32_t run = scan[tid] - mine;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t r = tid * per + j;
+      if (r < nr) {
+        const uint32_t h = off[r];
+        off[r] = run;
+        run += h;
+      }
+    }
+    if (tid == 0) off[nr] = total;
+    __syncthreads();
+    auto slot = [&](uint32_t i) -> uint64_t {
+      const uint32_t t = i / S, k = i - t * S;
+      return hb + ((uint64_t)(k >> 2) * kHpLanes + t) * 4 + (k & 3u);
+    };
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t r = tid * per + j;
+      if (r >= nr) continue;
+      const uint32_t first = off[r], count = off[r + 1] - first;
+      uint32_t h = 0;
+      for (uint64_t k = a.xptr[r0 + r], e = a.xptr[r0 + r + 1]; k < e; ++k) {
+        const uint32_t c = a.col[k];
+        if (c < a.nhot && !(a.skip_bias && c == 0)) {
+          const uint64_t at = slot(first + h);
+          ++h;
+          a.hcol[at] = (uint16_t)(c | (h == count ? 0x8000u : 0u));
+          if (a.hval) a.hval[at] = a.val[k];
+        }
+      }
+      if (h == 0) {  // a row without hot entries: one filler word that ends the row
+        const uint64_t at = slot(first);
+        a.hcol[at] = (uint16_t)(a.nhot | 0x8000u);
+        if (a.hval) a.hval[at] = 0.0f;
+      }
+    }
+    for (uint32_t i = total + tid; i < S * kHpLanes; i += kHpBuildThreads) {  // the lanes' runs are padded to equal length
+      const uint64_t at = slot(i);
+      a.hcol[at] = (uint16_t)a.nhot;
+      if (a.hval) a.hval[at] = 0.0f;
+    }
+    if (tid < kHpLanes) {
+      // the row that holds word tid * S: the last row whose offset is <= that word
+      const uint32_t pos = tid * S;
+      uint32_t lo = 0, hi = nr;  // off[lo] <= pos < off[hi] once pos < total
+      if (pos >= total) lo = 0;
+      else
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (off[mid] <= pos) lo = mid;
+          else hi = mid;
+        }
+      a.hfirst[p * kHpLanes + tid] = (uint16_t)lo;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- column stream of the transposed sweep -----------------------------------------------------
+
+struct TcBuildArgs {
+  const uint64_t *xptr;   // source form: compact rows of a relabelled set, else the plain rows
+  const uint32_t *col;
+  const float *val;
+  uint64_t nrows;
+  uint32_t ncols;         // stored ids below this go to the stream
+  int skip_bias;
+  uint32_t *len;          // count pass: [npanels] words, then [npanels] entries
+  const uint64_t *tbase;  // fill pass
+  uint16_t *tw;
+  float *tv;
+  uint16_t *tfirst;
+};
+
+// One workgroup per panel of kTcRows rows: counts the panel's entries per column, lays the columns
+// out one after another (an empty column takes one filler word) and scatters the entries.
+template <bool FILL>
+__global__ void __launch_bounds__(kTcLanes) k_tcbuild(TcBuildArgs a) {
+  extern __shared__ uint32_t tc_sh[];  // [ncols] counts / cursors, [ncols + 1] word offsets, [kTcLanes] scan scratch
+  uint32_t *cnt = tc_sh;
+  uint32_t *off = tc_sh + a.ncols;
+  uint32_t *scan = off + a.ncols + 1;
+  const uint64_t npanels = (a.nrows + kTcRows - 1) / kTcRows;
+  const int tid = threadIdx.x;
+  const uint32_t per = (a.ncols + kTcLanes - 1) / kTcLanes;  // consecutive columns per thread
+  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+    const uint64_t r0 = p * kTcRows;
+    const uint32_t nr = (uint32_t)(a.nrows - r0 < kTcRows ? a.nrows - r0 : kTcRows);
+    for (uint32_t c = tid; c < a.ncols; c += kTcLanes) cnt[c] = 0;
+    __syncthreads();
+    for (uint32_t r = tid; r < nr; r += kTcLanes)
+      for (uint64_t k = a.xptr[r0 + r], e = a.xptr[r0 + r + 1]; k < e; ++k) {
+        const uint32_t c = a.col[k];
+        if (c < a.ncols && !(a.skip_bias && c == 0)) atomicAdd(&cnt[c], 1u);
+      }
+    __syncthreads();
+    uint32_t mine = 0, mine_entries = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t c = tid * per + j;
+      if (c < a.ncols) {
+        mine += cnt[c] ? cnt[c] : 1u;
+        mine_entries += cnt[c];
+      }
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < kTcLanes; o <<= 1) {
+      const uint32_t add = tid >= o ? scan[tid - o] : 0u;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    const uint32_t total = scan[kTcLanes - 1];
+    if (!FILL) {
+      if (tid == 0) {
+        a.len[p] = total;
+        a.len[npanels + p] = 0;
+      }
+      __syncthreads();
+      if (mine_entries) atomicAdd(&a.len[npanels + p], mine_entries);
+      __syncthreads();
+      continue;
+    }
+    const uint64_t tb = a.tbase[p];
+    const uint32_t S = (uint32_t)((a.tbase[p + 1] - tb) / kTcLanes);  // words per lane, a multiple of 4
+    auto slot = [&](uint32_t i) -> uint64_t {
+      const uint32_t t = i / S, k = i - t * S;
+      return tb + ((uint64_t)(k >> 2) * kTcLanes + t) * 4 + (k & 3u);
+    };
+    uint32_t run = scan[tid] - mine;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t c = tid * per + j;
+      if (c < a.ncols) {
+        off[c] = run;
+        if (cnt[c] == 0) {  // a column without entries in this panel: one filler word that ends the column
+          const uint64_t at = slot(run);
+          a.tw[at] = (uint16_t)(kTcRows | 0x8000u);
+          if (a.tv) a.tv[at] = 0.0f;
+          run += 1;
+        } else {
+          run += cnt[c];
+          cnt[c] = 0;  // becomes the column's cursor
+        }
+      }
+    }
+    if (tid == 0) off[a.ncols] = total;
+    __syncthreads();
+    for (uint32_t r = tid; r < nr; r += kTcLanes)
+      for (uint64_t k = a.xptr[r0 + r], e = a.xptr[r0 + r + 1]; k < e; ++k) {
+        const uint32_t c = a.col[k];
+        if (c < a.ncols && !(a.skip_bias && c == 0)) {
+          const uint32_t i = atomicAdd(&cnt[c], 1u), n = off[c + 1] - off[c];
+          const uint64_t at = slot(off[c] + i);
+          a.tw[at] = (uint16_t)(r | (i + 1 == n ? 0x8000u : 0u));
+          if (a.tv) a.tv[at] = a.val[k];
+        }
+      }
+    for (uint32_t i = total + tid; i < S * kTcLanes; i += kTcLanes) {  // the lanes' runs are padded to equal length
+      const uint64_t at = slot(i);
+      a.tw[at] = (uint16_t)kTcRows;
+      if (a.tv) a.tv[at] = 0.0f;
+    }
+    {
+      // the column that holds word tid * S: the last column whose offset is <= that word
+      const uint32_t pos = tid * S;
+      uint32_t lo = 0, hi = a.ncols;
+      if (pos < total)
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (off[mid] <= pos) lo = mid;
+          else hi = mid;
+        }
+      a.tfirst[p * kTcLanes + tid] = (uint16_t)lo;
+    }
+    __syncthreads();
+  }
+}
+
+int build_column_stream(admm_csr *csr, bool want) {
+  admm_ctx *ctx = csr->ctx;
+  for (void **p : {(void **)&csr->d_tcw, (void **)&csr->d_tcv, (void **)&csr->d_tcbase, (void **)&csr->d_tcfirst}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  csr->has_tc = false;
+  csr->tc_cols = 0;
+  csr->tc_words = csr->tc_entries = 0;
+  if (!want || csr->nrows == 0 || csr->nnz == 0) return ADMM_OK;
+  const uint32_t ncols = (uint32_t)std::min<uint64_t>(kFpHot, csr->dim);
+  const uint64_t npanels = (csr->nrows + kTcRows - 1) / kTcRows;
+  const int grid = (int)std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 2);
+  const size_t lds = sizeof(uint32_t) * (2 * (size_t)ncols + 1 + kTcLanes);
+  static bool raised[64] = {};
+  if (!raised[ctx->device & 63]) {
+    for (const void *fn : {reinterpret_cast<const void *>(&k_tcbuild<false>), reinterpret_cast<const void *>(&k_tcbuild<true>)})
+      ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(sizeof(uint32_t) * (2 * (size_t)kFpHot + 1 + kTcLanes))));
+    raised[ctx->device & 63] = true;
+  }
+  TcBuildArgs a{};
+  a.xptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
+  a.col = csr->hot_dense ? csr->d_ccol : csr->d_col;
+  a.val = csr->hot_dense ? csr->d_cval : csr->d_val;
+  a.nrows = csr->nrows;
+  a.ncols = ncols;
+  a.skip_bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
+  uint32_t *d_len = nullptr;
+  ADMM_HIP_CHECK(hipMalloc(&d_len, sizeof(uint32_t) * 2 * npanels));
+  a.len = d_len;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tcbuild<false>), dim3(grid), dim3(kTcLanes), lds, ctx->stream, a);
+  std::vector<uint32_t> len(2 * npanels);
+  hipError_t ce = hipGetLastError();
+  if (ce == hipSuccess)
+    ce = hipMemcpyAsync(len.data(), d_len, sizeof(uint32_t) * 2 * npanels, hipMemcpyDeviceToHost, ctx->stream);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+  hipFree(d_len);
+  ADMM_HIP_CHECK(ce);
+  std::vector<uint64_t> tbase(npanels + 1);
+  tbase[0] = 0;
+  uint64_t entries = 0;
+  for (uint64_t p = 0; p < npanels; ++p) {
+    const uint64_t per_lane = ((uint64_t)len[p] + kTcLanes - 1) / kTcLanes;
+    tbase[p + 1] = tbase[p] + ((per_lane + 3) & ~3ull) * kTcLanes;
+    entries += len[npanels + p];
+  }
+  const uint64_t words = tbase[npanels];
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_tcbase, sizeof(uint64_t) * (npanels + 1)));
+  ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_tcbase, tbase.data(), sizeof(uint64_t) * (npanels + 1), hipMemcpyHostToDevice, ctx->stream));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_tcw, sizeof(uint16_t) * (words + 8)));
+  if (a.val) ADMM_HIP_CHECK(hipMalloc(&csr->d_tcv, sizeof(float) * (words + 8)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_tcfirst, sizeof(uint16_t) * npanels * kTcLanes));
+  a.len = nullptr;
+  a.tbase = csr->d_tcbase;
+  a.tw = csr->d_tcw;
+  a.tv = csr->d_tcv;
+  a.tfirst = csr->d_tcfirst;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tcbuild<true>), dim3(grid), dim3(kTcLanes), lds, ctx->stream, a);
+  ADMM_HIP_CHECK(hipGetLastError());
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  csr->tc_cols = ncols;
+  csr->tc_words = words;
+  csr->tc_entries = entries;
+  csr->has_tc = true;
+  if (getenv("ADMM_VERBOSE"))
+    fprintf(stderr, "[admm_hip] column stream: %llu words for %llu entries (ids < %u)\n", (unsigned long long)words,
+            (unsigned long long)entries, ncols);
+  return ADMM_OK;
+}
+
 __global__ void __launch_bounds__(256) k_maxrowlen(const uint64_t *__restrict__ rowptr, uint64_t nrows,
                                                    double *__restrict__ partials) {
   __shared__ unsigned long long sh[4];
@@ -556,7 +889,8 @@ __global__ void __launch_bounds__(256) k_maxrowlen(const uint64_t *__restrict__ 
 
 int build_forward_panels(admm_csr *csr) {
   admm_ctx *ctx = csr->ctx;
-  for (void **p : {(void **)&csr->d_fcol, (void **)&csr->d_frow, (void **)&csr->d_fval, (void **)&csr->d_fsplit}) {
+  for (void **p : {(void **)&csr->d_fcol, (void **)&csr->d_frow, (void **)&csr->d_fval, (void **)&csr->d_fptr,
+                   (void **)&csr->d_hcol, (void **)&csr->d_hval, (void **)&csr->d_hbase, (void **)&csr->d_hfirst}) {
     if (*p) hipFree(*p);
     *p = nullptr;
   }
@@ -567,8 +901,10 @@ int build_forward_panels(admm_csr *csr) {
     if (env && env[0] == '0') return ADMM_OK;
   }
   const uint32_t R = 4096;
+  uint32_t nhot = (uint32_t)std::min<uint64_t>(kFpHot, csr->dim);
+  if (const char *env = getenv("ADMM_FORWARD_HOT"))  // test aid: a smaller hot range, so that small sets have entries outside it
+    nhot = (uint32_t)std::min<uint64_t>(nhot, std::strtoull(env, nullptr, 10));
   const bool skip_bias = csr->has_bias && !csr->hot_dense;
-  const uint64_t total = csr->hot_dense ? csr->cnnz : (skip_bias ? csr->nnz - csr->nrows : csr->nnz);
   // longest stored row (mask-held entries included): bounds a margin's magnitude
   {
     const int g = grid_for(csr->nrows, 256, ctx->cu_count * 8);
@@ -583,30 +919,49 @@ int build_forward_panels(admm_csr *csr) {
     csr->fp_lenbits = 0;
     while (std::ldexp(1.0, csr->fp_lenbits) < m + 1.0) ++csr->fp_lenbits;
   }
-  uint32_t bin_shift = 0;
-  while (((csr->dim + (1ull << bin_shift) - 1) >> bin_shift) > kFpMaxBins) ++bin_shift;
-  const uint32_t nbins = (uint32_t)((csr->dim + (1ull << bin_shift) - 1) >> bin_shift);
+  const uint64_t npanels = (csr->nrows + R - 1) / R;
+  const int grid = (int)std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 4);
+  const float *src_val = csr->hot_dense ? csr->d_cval : csr->d_val;
+  // ---- sizes: words of every panel's hot stream, entries outside it
+  HpBuildArgs h{};
+  h.xptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
+  h.col = csr->hot_dense ? csr->d_ccol : csr->d_col;
+  h.val = src_val;
+  h.nrows = csr->nrows;
+  h.panel_rows = R;
+  h.nhot = nhot;
+  h.skip_bias = skip_bias ? 1 : 0;
+  uint32_t *d_len = nullptr;
+  ADMM_HIP_CHECK(hipMalloc(&d_len, sizeof(uint32_t) * 2 * npanels));
+  h.hlen = d_len;
+  h.clen = d_len + npanels;
+  hipLaunchKernelGGL(k_hpcount, dim3(grid), dim3(kHpBuildThreads), 0, ctx->stream, h);
+  std::vector<uint32_t> len(2 * npanels);
+  hipError_t ce = hipGetLastError();
+  if (ce == hipSuccess)
+    ce = hipMemcpyAsync(len.data(), d_len, sizeof(uint32_t) * 2 * npanels, hipMemcpyDeviceToHost, ctx->stream);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+  hipFree(d_len);
+  ADMM_HIP_CHECK(ce);
+  std::vector<uint64_t> hbase(npanels + 1), fptr(npanels + 1);
+  hbase[0] = fptr[0] = 0;
+  for (uint64_t p = 0; p < npanels; ++p) {
+    const uint64_t per_lane = ((uint64_t)len[p] + kHpLanes - 1) / kHpLanes;
+    hbase[p + 1] = hbase[p] + ((per_lane + 3) & ~3ull) * kHpLanes;
+    fptr[p + 1] = fptr[p] + len[npanels + p];
+  }
+  const uint64_t hwords = hbase[npanels], total = fptr[npanels];
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_hbase, sizeof(uint64_t) * (npanels + 1)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_fptr, sizeof(uint64_t) * (npanels + 1)));
+  ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_hbase, hbase.data(), sizeof(uint64_t) * (npanels + 1), hipMemcpyHostToDevice, ctx->stream));
+  ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_fptr, fptr.data(), sizeof(uint64_t) * (npanels + 1), hipMemcpyHostToDevice, ctx->stream));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_hcol, sizeof(uint16_t) * (hwords + 8)));
+  if (src_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_hval, sizeof(float) * (hwords + 8)));
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_hfirst, sizeof(uint16_t) * npanels * kHpLanes));
   ADMM_HIP_CHECK(hipMalloc(&csr->d_fcol, sizeof(uint32_t) * (total + 8)));
   ADMM_HIP_CHECK(hipMalloc(&csr->d_frow, sizeof(uint16_t) * (total + 8)));
-  const float *src_val = csr->hot_dense ? csr->d_cval : csr->d_val;
   if (src_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_fval, sizeof(float) * (total + 8)));
   if (!csr->d_fp_shift) ADMM_HIP_CHECK(hipMalloc(&csr->d_fp_shift, sizeof(int) * 2));
-  FpBuildArgs a{};
-  a.xptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
-  a.col = csr->hot_dense ? csr->d_ccol : csr->d_col;
-  a.val = src_val;
-  a.nrows = csr->nrows;
-  a.panel_rows = R;
-  a.bin_shift = bin_shift;
-  a.nbins = nbins;
-  a.split_bin = (kFpHot + (1u << bin_shift) - 1) >> bin_shift;
-  ADMM_HIP_CHECK(hipMalloc(&csr->d_fsplit, sizeof(uint32_t) * ((csr->nrows + R - 1) / R + 1)));
-  a.split = csr->d_fsplit;
-  a.skip_bias = skip_bias ? 1 : 0;
-  a.fcol = csr->d_fcol;
-  a.frow = csr->d_frow;
-  a.fval = csr->d_fval;
-  const size_t lds = sizeof(uint32_t) * (nbins + kFpBuildThreads);
   static bool raised[64] = {};
   if (!raised[ctx->device & 63]) {
     for (const void *fn : {reinterpret_cast<const void *>(&k_fpbuild), reinterpret_cast<const void *>(&k_fpsort)})
@@ -614,19 +969,51 @@ int build_forward_panels(admm_csr *csr) {
                                          (int)(sizeof(uint32_t) * (kFpMaxBins + kFpBuildThreads))));
     raised[ctx->device & 63] = true;
   }
-  const uint64_t npanels = (csr->nrows + R - 1) / R;
-  const int grid = (int)std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 4);
-  hipLaunchKernelGGL(k_fpbuild, dim3(grid), dim3(kFpBuildThreads), lds, ctx->stream, a);
+  // ---- hot stream
+  h.hlen = h.clen = nullptr;
+  h.hbase = csr->d_hbase;
+  h.hcol = csr->d_hcol;
+  h.hval = csr->d_hval;
+  h.hfirst = csr->d_hfirst;
+  hipLaunchKernelGGL(k_hpfill, dim3(grid), dim3(kHpBuildThreads), sizeof(uint32_t) * (R + 1 + kHpBuildThreads), ctx->stream, h);
   ADMM_HIP_CHECK(hipGetLastError());
-  if (bin_shift > 0) {  // bins of one column are in order already
-    hipLaunchKernelGGL(k_fpsort, dim3(grid), dim3(kFpBuildThreads), lds, ctx->stream, a);
+  // ---- the entries outside it, in column order
+  uint32_t bin_shift = 0;
+  while (((csr->dim + (1ull << bin_shift) - 1) >> bin_shift) > kFpMaxBins) ++bin_shift;
+  const uint32_t nbins = (uint32_t)((csr->dim + (1ull << bin_shift) - 1) >> bin_shift);
+  if (total > 0) {
+    FpBuildArgs a{};
+    a.xptr = h.xptr;
+    a.col = h.col;
+    a.val = src_val;
+    a.nrows = csr->nrows;
+    a.panel_rows = R;
+    a.bin_shift = bin_shift;
+    a.nbins = nbins;
+    a.nhot = nhot;
+    a.fptr = csr->d_fptr;
+    a.skip_bias = skip_bias ? 1 : 0;
+    a.fcol = csr->d_fcol;
+    a.frow = csr->d_frow;
+    a.fval = csr->d_fval;
+    const size_t lds = sizeof(uint32_t) * (nbins + kFpBuildThreads);
+    hipLaunchKernelGGL(k_fpbuild, dim3(grid), dim3(kFpBuildThreads), lds, ctx->stream, a);
     ADMM_HIP_CHECK(hipGetLastError());
+    if (bin_shift > 0) {  // bins of one column are in order already
+      hipLaunchKernelGGL(k_fpsort, dim3(grid), dim3(kFpBuildThreads), lds, ctx->stream, a);
+      ADMM_HIP_CHECK(hipGetLastError());
+    }
   }
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   csr->fp_rows = R;
   csr->fp_bin_cols = 1u << bin_shift;
+  csr->fp_hot = nhot;
   csr->fp_nnz = total;
+  csr->hp_words = hwords;
   csr->has_fp = true;
+  if (getenv("ADMM_VERBOSE"))
+    fprintf(stderr, "[admm_hip] forward panels: %llu rows, hot stream %llu words (ids < %u), %llu entries outside it\n",
+            (unsigned long long)csr->nrows, (unsigned long long)hwords, nhot, (unsigned long long)total);
   return ADMM_OK;
 }
 
@@ -662,7 +1049,8 @@ static void free_csr(admm_csr *c) {
   void *ptrs[] = {c->d_rowptr, c->d_col, c->d_val,  c->d_label, c->d_rowbuf, c->d_margin, c->d_dmargin, c->d_cache_x, c->d_cache_off, c->d_cache_gl, c->d_tptr,
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol,
-                  c->d_fcol,   c->d_frow, c->d_fval, c->d_fp_shift, c->d_fsplit};
+                  c->d_fcol,   c->d_frow, c->d_fval, c->d_fp_shift, c->d_fptr, c->d_hcol, c->d_hval, c->d_hbase, c->d_hfirst,
+                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;
@@ -790,7 +1178,7 @@ extern "C" int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t
     *csr_bytes = 8 * (csr->nrows + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * csr->nrows;
   if (transposed_bytes)
     *transposed_bytes = csr->has_t ? 8 * (csr->npanels * csr->nblocks + 1) + 6 * csr->tnnz +
-                                         (csr->d_tval ? 4 * csr->tnnz : 0)
+                                         (csr->d_tval ? 4 * csr->tnnz : 0) + (csr->d_tcv ? 6 : 2) * csr->tc_words
                                    : 0;
   return ADMM_OK;
 }
@@ -799,12 +1187,15 @@ extern "C" int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]) {
   ADMM_REQUIRE(csr && out, "admm_csr_layout_bytes: NULL argument");
   const uint64_t n = csr->nrows;
   out[0] = 8 * (n + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * n;
-  if (csr->has_fp)  // row-panel copy: masks + (column u32, row u16 [, value]) per remaining entry + labels
-    out[1] = (csr->hot_dense ? 8 * n * (1 + kWarmWords) : 0) + 6 * csr->fp_nnz + (csr->d_fval ? 4 * csr->fp_nnz : 0) + 4 * n;
+  if (csr->has_fp)  // row-panel copy: masks + hot stream (u16 [, value]) + (column u32, row u16 [, value]) per remaining entry + labels
+    out[1] = (csr->hot_dense ? 8 * n * (1 + kWarmWords) : 0) + (csr->d_hval ? 6 : 2) * csr->hp_words +
+             (csr->d_fval ? 10 : 6) * csr->fp_nnz + 4 * n;
   else
     out[1] = csr->hot_dense ? 8 * (n + 1) + 8 * n * (1 + kWarmWords) + 4 * csr->cnnz + (csr->d_cval ? 4 * csr->cnnz : 0) + 4 * n
                             : out[0];
-  out[2] = csr->has_t ? 8 * (csr->npanels * csr->nblocks + 1) + 6 * csr->tnnz + (csr->d_tval ? 4 * csr->tnnz : 0) : 0;
+  out[2] = csr->has_t ? 8 * (csr->npanels * csr->nblocks + 1) + 6 * csr->tnnz + (csr->d_tval ? 4 * csr->tnnz : 0) +
+                            (csr->d_tcv ? 6 : 2) * csr->tc_words
+                      : 0;
   out[3] = (csr->d_rowbuf ? 4 * n : 0) + (csr->d_margin ? 4 * n : 0) + (csr->d_dmargin ? 4 * n : 0);
   return ADMM_OK;
 }
@@ -926,8 +1317,9 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
     *p = nullptr;
   }
 #undef RL_CHECK
-  // a transposed copy built earlier still holds the entries the mask now covers: rebuild it
-  if (csr->has_t && csr->hot_dense) return admm_csr_build_transposed(csr, csr->panel_rows, csr->col_block);
+  // a transposed copy built earlier still holds the entries the mask now covers, and a column stream
+  // is in the old numbering: rebuild
+  if (csr->has_t && (csr->hot_dense || csr->has_tc)) return build_transposed(csr, csr->panel_rows, csr->col_block, csr->has_tc);
   return ADMM_OK;
 }
 
@@ -938,6 +1330,16 @@ extern "C" int admm_csr_destroy(admm_csr *csr) {
 
 extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block) {
   ADMM_REQUIRE(csr, "admm_csr_build_transposed: csr is NULL");
+  // automatic panels = the copy is for whole-set sweeps: its most frequent columns go to the column
+  // stream.  A caller that names the panel size sweeps panel ranges (mini-batches), which read cells only.
+  bool stream = panel_rows == 0;
+  if (const char *env = getenv("ADMM_COLUMN_STREAM"))  // 0: never; 2: also with a named panel size (test aid)
+    stream = env[0] != '0' && (stream || env[0] == '2');
+  return admm_impl::build_transposed(csr, panel_rows, col_block, stream);
+}
+
+namespace admm_impl {
+int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool stream) {
   admm_ctx *ctx = csr->ctx;
   if (col_block == 0) col_block = 8192;
   ADMM_REQUIRE(col_block <= 16384 && col_block >= 64 && (col_block % 64) == 0,
@@ -962,6 +1364,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   }
   csr->has_t = false;
   csr->cache_valid = false;
+  ADMM_TRY(build_column_stream(csr, stream));
   csr->panel_rows = panel_rows;
   csr->col_block = col_block;
   csr->nblocks = (uint32_t)((csr->dim + col_block - 1) / col_block);
@@ -983,6 +1386,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   a.nblocks = csr->nblocks;
   a.skip_bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
   a.hot_dense = csr->hot_dense ? 1 : 0;
+  a.stream_cols = csr->tc_cols;
   a.cell_count = d_cnt;
   const uint64_t chunks = csr->npanels * ((panel_rows + kChunkRows - 1) / kChunkRows);
   const int grid = grid_for(chunks * 256, 256, ctx->cu_count * 8);
@@ -1002,7 +1406,7 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
   }
   csr->h_tptr[ncells] = run;
   csr->tnnz = run;
-  const uint64_t expect = csr->hot_dense ? csr->cnnz : (csr->has_bias ? csr->nnz - csr->nrows : csr->nnz);
+  const uint64_t expect = (csr->hot_dense ? csr->cnnz : (csr->has_bias ? csr->nnz - csr->nrows : csr->nnz)) - csr->tc_entries;
   if (run != expect) {
     hipFree(d_cnt);
     set_error("admm_csr_build_transposed: counted %llu entries, expected %llu",
@@ -1041,15 +1445,18 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
     csr->vmax = (float)std::max(1.0, m);
   }
   int need = 0;
-  while ((1ull << need) < panel_rows && need < 40) ++need;
+  while ((1ull << need) < csr->nrows && need < 40) ++need;
   int vbits = 0;
   while (std::ldexp(1.0, vbits) < (double)csr->vmax) ++vbits;
-  csr->fx_shift = std::max(8, std::min(40, 61 - need - vbits));
+  // a column's sum over the whole set stays below 2^61, and its sum over one panel of the column
+  // stream below 2^50 (the stream adds those up in doubles, exactly)
+  csr->fx_shift = std::max(8, std::min(50 - 13, 61 - need) - vbits);
   csr->has_t = true;
   ADMM_TRY(ensure_taccum(csr));
   ADMM_TRY(build_forward_panels(csr));
   return ADMM_OK;
 }
+}  // namespace admm_impl
 
 extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_csr **out) {
   ADMM_REQUIRE(ctx && spec && out, "admm_csr_synth: NULL argument");

@@ -49,6 +49,10 @@ constexpr uint32_t kMaskCols = 64u * (1 + kWarmWords);
 // leading entries of the gathered vector that the row-panel forward sweep keeps in LDS (a multiple
 // of every bin width the copy's builder can choose)
 constexpr uint32_t kFpHot = 8192;
+constexpr int kHpLanes = 512;  // lanes that share a panel's hot stream = threads of the sweep's workgroup
+// column stream of the transposed sweep: rows per panel (row ids take 13 bits of a word), lanes per panel
+constexpr uint32_t kTcRows = 8192;
+constexpr int kTcLanes = 1024;
 
 constexpr int kMaxPartialBlocks = 4096;  // reduction partial slots per output scalar
 constexpr int kPartialScalars = 8;       // scalars a reducing kernel may emit
@@ -131,19 +135,42 @@ struct admm_csr {
   uint16_t *d_tcol = nullptr;
   float *d_tval = nullptr;  // nullptr when d_val is
   std::vector<uint64_t> h_tptr;
-  // Row-panel copy read by the forward sweep of a whole set: rows cut into panels of fp_rows rows, a
-  // panel's entries (those not held by the row masks; the bias column of a set without masks is
-  // left out) stored contiguously in the order of their stored column ids (frequency ranks in a
-  // relabelled set), as (stored column id u32, row inside the panel u16 [, value f32]).
-  // d_fsplit[p] = how many of panel p's entries have a column id below kFpHot (they come first).  Panel p starts at
-  // X[min(p fp_rows, nrows)] - (bias left out ? that row index : 0) with X = crowptr or rowptr.
+  // Column stream (whole-set sweeps of a copy built with automatic panels): the entries whose stored
+  // column id is below tc_cols are not in the cells above.  Rows are cut into panels of kTcRows; a
+  // panel's entries are 16-bit words in column order (row inside the panel, bit 15 set on the last
+  // word of its column; a column without entries in the panel holds one filler word with row
+  // kTcRows), cut into kTcLanes equal runs and interleaved like the forward sweep's hot stream:
+  // word i of panel p is at d_tcbase[p] + ((k / 4) kTcLanes + t) 4 + k % 4, S = words per lane,
+  // t = i / S, k = i % S; d_tcfirst[p kTcLanes + t] is the column lane t starts in.
+  bool has_tc = false;
+  uint32_t tc_cols = 0;
+  uint16_t *d_tcw = nullptr;
+  float *d_tcv = nullptr;
+  uint64_t *d_tcbase = nullptr;
+  uint16_t *d_tcfirst = nullptr;
+  uint64_t tc_words = 0, tc_entries = 0;
+  // Row-panel copy read by the forward sweep of a whole set: rows cut into panels of fp_rows rows.  The
+  // entries the row masks do not hold (and, in a set without masks, not the bias column) are in one
+  // of two forms, by stored column id (a frequency rank in a relabelled set):
+  // * id < fp_hot, the "hot stream": the panel's rows one after another, every entry a 16-bit word
+  //   (id, bit 15 set on the last entry of its row; a row without such entries holds one filler word
+  //   with id fp_hot), cut into kHpLanes equal runs, one per lane of the sweep's workgroup, and
+  //   stored so that the lanes' k-th groups of four entries are adjacent: entry i of the panel is at
+  //   d_hbase[p] + ((k / 4) kHpLanes + t) 4 + k % 4 with S = (d_hbase[p+1] - d_hbase[p]) / kHpLanes,
+  //   t = i / S, k = i % S; d_hfirst[p kHpLanes + t] is the row lane t starts in.
+  // * the rest: contiguous per panel from d_fptr[p], in the order of their ids, as (id u32, row
+  //   inside the panel u16 [, value f32]).
   bool has_fp = false;
-  uint32_t fp_rows = 0, fp_bin_cols = 0;
+  uint32_t fp_rows = 0, fp_bin_cols = 0, fp_hot = 0;
   uint32_t *d_fcol = nullptr;
   uint16_t *d_frow = nullptr;
   float *d_fval = nullptr;
-  uint32_t *d_fsplit = nullptr;
-  uint64_t fp_nnz = 0;
+  uint64_t *d_fptr = nullptr;
+  uint16_t *d_hcol = nullptr;
+  float *d_hval = nullptr;
+  uint64_t *d_hbase = nullptr;
+  uint16_t *d_hfirst = nullptr;
+  uint64_t fp_nnz = 0, hp_words = 0;  // entries of the second form; words of the first (fillers included)
   int fp_lenbits = 0;         // ceil(log2(longest stored row + 1))
   int *d_fp_shift = nullptr;  // fixed-point shift of the margins, chosen on the device per sweep
   // per-coordinate accumulators of the transposed sweep: 64-bit fixed point (value * 2^fx_shift),
@@ -175,6 +202,7 @@ int finish_partials(admm_ctx *ctx, int nscalars, int nblocks);
 
 int ensure_rowbuf(admm_csr *csr);
 int build_forward_panels(admm_csr *csr);  // csr.hip
+int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool column_stream);  // csr.hip
 int ensure_taccum(admm_csr *csr);
 
 // sweeps (sweep.hip)

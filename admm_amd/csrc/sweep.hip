@@ -592,33 +592,40 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 //
 // The row-major sweep above gathers one weight per stored entry from a vector of `dim` floats in
-// row order: 64 lanes, 64 different cache lines.  This form turns the access around: a workgroup
-// owns a panel of fp_rows rows and keeps their margins in LDS as 64-bit fixed point; the panel's
-// entries are stored in column order (up to a bin's width), so 64 consecutive entries gather their
-// weights from a few adjacent lines, and the scattered access -- one add per entry to the margin
-// of the entry's row -- goes to LDS, where an integer atomic costs one lane-clock.  Integer adds
-// commute: the margins do not depend on the order of the entries, and a sweep is bit-reproducible.
-// The fixed-point shift is chosen per sweep on the device from max |w| (k_wsum_absmax, k_fp_shift),
-// the largest |value| and the longest row, so that no row sum can leave 62 bits.
+// row order: 64 lanes, 64 different cache lines.  Here a workgroup owns a panel of fp_rows rows and
+// keeps their margins in LDS as 64-bit fixed point.  The panel's entries come in two forms:
+// * entries whose stored column id is below nhot (the bulk of a frequency-relabelled set) are 16-bit
+//   words in row order, cut into one run per lane.  The weights of those columns sit in LDS, already
+//   in fixed point; a lane sums a row's table entries in a register and adds to the row's margin
+//   once per row -- no memory gather and no atomic per entry.
+// * the other entries are stored in column order (up to a bin's width), so 64 consecutive entries
+//   gather their weights from a few adjacent lines, and the scattered access -- one add per entry
+//   to the margin of the entry's row -- goes to LDS, where an integer atomic costs one lane-clock.
+// Integer adds commute: the margins do not depend on the order of the entries, and a sweep is
+// bit-reproducible.  The fixed-point shift is chosen per sweep on the device from max |w|
+// (k_wsum_absmax, k_fp_shift), the largest |value| and the longest row, so that no row sum can
+// reach 2^50.
 //
 // Entries in the most frequent kMaskCols columns of a relabelled set are not in the copy: they are
 // bits of the row's mask words, summed when the panel's margins are initialised, and their part of
 // X^T r is accumulated in the epilogue (as in the row-major sweep).
 
-constexpr int kRpThreads = 512;
+constexpr int kRpThreads = kHpLanes;
 
 __device__ inline unsigned long long rp_to_fx(float x, float scale) { return (unsigned long long)(long long)(x * scale); }
 
 struct RpArgs {
-  const uint32_t *fcol;
+  const uint16_t *hcol;    // hot stream (ids below nhot; bit 15: last entry of its row)
+  const float *hval;
+  const uint64_t *hbase;   // per panel: first word of its hot stream
+  const uint16_t *hfirst;  // per panel and lane: the row the lane's run starts in
+  const uint32_t *fcol;    // the entries outside the hot stream, in column order per panel
   const uint16_t *frow;
   const float *fval;
-  const uint64_t *xptr;    // crowptr (relabelled set) or rowptr: panel p starts at xptr[p R] - (skip_bias ? p R : 0)
-  int skip_bias;
+  const uint64_t *fptr;    // per panel: first of those entries
   const float *label;
   const uint64_t *hmask, *hwarm;  // nullptr: no mask tier
   const uint32_t *perm;    // stored id -> caller's id (relabelled sets), for the column sums' destination
-  const uint32_t *split;   // per panel: entries whose column is below nhot (they come first)
   uint32_t nhot;           // leading entries of w cached in LDS
   const float *w;          // gathered vector in the set's stored column order
   const int *shift;        // fixed-point shift of this sweep
@@ -631,10 +638,19 @@ struct RpArgs {
   float gscale;
 };
 
+// An integer-valued double of magnitude below 2^51 as a 64-bit integer: adding 1.5 * 2^52 leaves the
+// integer (offset by 2^51) in the low mantissa bits.
+__device__ inline unsigned long long rp_d2fx(double s) {
+  return (unsigned long long)(__double_as_longlong(s + 6755399441055744.0) - 0x4338000000000000ll);
+}
+
 template <int MODE, bool HASVAL>
 __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
-  extern __shared__ unsigned long long rp_acc[];                     // [panel_rows] margins, fixed point; then float hot[nhot]
-  float *hot = reinterpret_cast<float *>(rp_acc + a.panel_rows);     // leading entries of w (the mask columns first)
+  extern __shared__ unsigned long long rp_acc[];                     // [panel_rows] margins, fixed point; then float hot[nhot + 1]
+  // leading entries of w: as they are (sets with values) or times 2^shift with the fraction dropped
+  // (pattern sets: an entry's addend is then the table entry itself); hot[nhot] = 0 for filler words
+  float *hot = reinterpret_cast<float *>(rp_acc + a.panel_rows);
+  __shared__ float raw[kMaskCols];                                   // weights of the mask columns
   __shared__ float tab[8 * 256];                                     // byte of the first mask word -> sum of its weights
   __shared__ unsigned long long wacc[kMaskCols];                     // X^T r of the mask columns, this workgroup
   __shared__ double shred[kRpThreads / 64];
@@ -646,8 +662,15 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   const int shift = *a.shift;
   const float scale = ldexpf(1.0f, shift);
   const double inv_scale = ldexp(1.0, -shift);
-  for (uint32_t j = tid; j < a.nhot; j += kRpThreads) hot[j] = a.w[j];
-  if (tid < (int)kMaskCols) wacc[tid] = 0ull;
+  for (uint32_t j = tid; j < a.nhot; j += kRpThreads) {
+    const float x = a.w[j];
+    hot[j] = HASVAL ? x : truncf(x * scale);
+  }
+  if (tid == 0) hot[a.nhot] = 0.0f;
+  if (tid < (int)kMaskCols) {
+    wacc[tid] = 0ull;
+    raw[tid] = dense ? a.w[tid] : 0.0f;  // a set with masks has at least kMaskCols columns
+  }
   __syncthreads();
   if (dense) {
     for (int i = tid; i < 8 * 256; i += kRpThreads) {
@@ -655,7 +678,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
       float t = 0.0f;
 #pragma unroll
       for (int bit = 0; bit < 8; ++bit)
-        if (byte & (1 << bit)) t += hot[8 * g + bit];
+        if (byte & (1 << bit)) t += raw[8 * g + bit];
       tab[i] = t;
     }
   }
@@ -682,7 +705,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         for (int w = 0; w < kWarmWords; ++w) {
           unsigned long long mw = a.hwarm[(r0 + r) * kWarmWords + w];
           while (mw) {
-            m0 += hot[64 * (w + 1) + __builtin_ctzll(mw)];
+            m0 += raw[64 * (w + 1) + __builtin_ctzll(mw)];
             mw &= mw - 1;
           }
         }
@@ -690,38 +713,60 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
       rp_acc[r] = rp_to_fx(m0, scale);
     }
     __syncthreads();
-    // ---- the panel's entries: stream, look up or gather, add.  Entries come in the order of their
-    // column ids: first those whose weight is in the LDS copy, then the rest, whose weights are
-    // gathered from memory -- adjacent lanes from the same or neighbouring cache lines.
+    // ---- hot stream: every lane walks its run of the panel's rows, sums a row's table entries in a
+    // register (exact: integer-valued doubles below 2^51) and adds the sum to the row's margin when
+    // the row ends; a run that ends inside a row leaves its part at the end
     {
-      const uint64_t rend = r0 + nr;
-      const uint64_t beg = a.xptr[r0] - (a.skip_bias ? r0 : 0), end = a.xptr[rend] - (a.skip_bias ? rend : 0);
-      const uint64_t mid = beg + a.split[p];
-      uint64_t k = beg + tid;
-      for (; k + 3 * kRpThreads < mid; k += 4 * kRpThreads) {
-        const uint32_t c0 = __builtin_nontemporal_load(a.fcol + k), c1 = __builtin_nontemporal_load(a.fcol + k + kRpThreads),
-                       c2 = __builtin_nontemporal_load(a.fcol + k + 2 * kRpThreads),
-                       c3 = __builtin_nontemporal_load(a.fcol + k + 3 * kRpThreads);
-        const uint32_t q0 = __builtin_nontemporal_load(a.frow + k), q1 = __builtin_nontemporal_load(a.frow + k + kRpThreads),
-                       q2 = __builtin_nontemporal_load(a.frow + k + 2 * kRpThreads),
-                       q3 = __builtin_nontemporal_load(a.frow + k + 3 * kRpThreads);
-        float x0 = hot[c0], x1 = hot[c1], x2 = hot[c2], x3 = hot[c3];
-        if (HASVAL) {
-          x0 *= __builtin_nontemporal_load(a.fval + k);
-          x1 *= __builtin_nontemporal_load(a.fval + k + kRpThreads);
-          x2 *= __builtin_nontemporal_load(a.fval + k + 2 * kRpThreads);
-          x3 *= __builtin_nontemporal_load(a.fval + k + 3 * kRpThreads);
+      const uint64_t hb = a.hbase[p];
+      const uint32_t nq = (uint32_t)((a.hbase[p + 1] - hb) / (4 * kRpThreads));  // groups of four words per lane
+      uint32_t row = a.hfirst[p * kRpThreads + tid];
+      const u32x2 *src = reinterpret_cast<const u32x2 *>(a.hcol + hb) + tid;
+      const f32x4 *vsrc = HASVAL ? reinterpret_cast<const f32x4 *>(a.hval + hb) + tid : nullptr;
+      double sum = 0.0;
+      auto step = [&](uint32_t e, float v) {
+        float x = hot[e & 0x7FFFu];
+        if (HASVAL) x = truncf((x * v) * scale);
+        sum += (double)x;
+        if (e & 0x8000u) {
+          atomicAdd(&rp_acc[row], rp_d2fx(sum));
+          sum = 0.0;
+          ++row;
         }
-        atomicAdd(&rp_acc[q0], rp_to_fx(x0, scale));
-        atomicAdd(&rp_acc[q1], rp_to_fx(x1, scale));
-        atomicAdd(&rp_acc[q2], rp_to_fx(x2, scale));
-        atomicAdd(&rp_acc[q3], rp_to_fx(x3, scale));
+      };
+      uint32_t q = 0;
+      for (; q + 2 <= nq; q += 2) {
+        const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kRpThreads);
+        const u32x2 c1 = __builtin_nontemporal_load(src + (uint64_t)(q + 1) * kRpThreads);
+        f32x4 v0 = {1.f, 1.f, 1.f, 1.f}, v1 = v0;
+        if (HASVAL) {
+          v0 = __builtin_nontemporal_load(vsrc + (uint64_t)q * kRpThreads);
+          v1 = __builtin_nontemporal_load(vsrc + (uint64_t)(q + 1) * kRpThreads);
+        }
+        step(c0.x & 0xFFFFu, v0.x);
+        step(c0.x >> 16, v0.y);
+        step(c0.y & 0xFFFFu, v0.z);
+        step(c0.y >> 16, v0.w);
+        step(c1.x & 0xFFFFu, v1.x);
+        step(c1.x >> 16, v1.y);
+        step(c1.y & 0xFFFFu, v1.z);
+        step(c1.y >> 16, v1.w);
       }
-      for (; k < mid; k += kRpThreads) {
-        const float x = hot[a.fcol[k]];
-        atomicAdd(&rp_acc[a.frow[k]], rp_to_fx(HASVAL ? x * a.fval[k] : x, scale));
+      for (; q < nq; ++q) {
+        const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kRpThreads);
+        f32x4 v0 = {1.f, 1.f, 1.f, 1.f};
+        if (HASVAL) v0 = __builtin_nontemporal_load(vsrc + (uint64_t)q * kRpThreads);
+        step(c0.x & 0xFFFFu, v0.x);
+        step(c0.x >> 16, v0.y);
+        step(c0.y & 0xFFFFu, v0.z);
+        step(c0.y >> 16, v0.w);
       }
-      k = mid + tid;
+      if (sum != 0.0) atomicAdd(&rp_acc[row], rp_d2fx(sum));
+    }
+    // ---- the other entries: stream, gather, add.  They come in the order of their column ids, so
+    // adjacent lanes gather from the same or neighbouring cache lines.
+    {
+      const uint64_t beg = a.fptr[p], end = a.fptr[p + 1];
+      uint64_t k = beg + tid;
       for (; k + 3 * kRpThreads < end; k += 4 * kRpThreads) {
         const uint32_t c0 = __builtin_nontemporal_load(a.fcol + k), c1 = __builtin_nontemporal_load(a.fcol + k + kRpThreads),
                        c2 = __builtin_nontemporal_load(a.fcol + k + 2 * kRpThreads),
@@ -859,7 +904,8 @@ __global__ void __launch_bounds__(256) k_wsum_absmax(const float *__restrict__ w
   if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
-// shift = the largest s with (longest row) * max |w v| * 2^s < 2^61, at most 40
+// shift = the largest s with (longest row) * max |w v| * 2^s < 2^50, at most 40: a margin, and every
+// partial sum of one, then is an integer below 2^51 in magnitude, which a double holds exactly
 __global__ void __launch_bounds__(256) k_fp_shift(const float *__restrict__ blockmax, int nblocks, float vmax, int lenbits,
                                                   int *__restrict__ shift_out) {
   __shared__ float sh[256];
@@ -876,7 +922,7 @@ __global__ void __launch_bounds__(256) k_fp_shift(const float *__restrict__ bloc
     int e = 0;
     if (top > 0.0f && top < 3.0e38f) frexpf(top, &e);  // top < 2^e
     else if (!(top < 3.0e38f)) e = 128;
-    int s = 61 - lenbits - e;
+    int s = 50 - lenbits - e;
     s = s > 40 ? 40 : (s < -60 ? -60 : s);
     *shift_out = s;
   }
@@ -914,12 +960,15 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
     ADMM_HIP_CHECK(hipGetLastError());
   }
   RpArgs a{};
+  a.hcol = csr->d_hcol;
+  a.hval = csr->d_hval;
+  a.hbase = csr->d_hbase;
+  a.hfirst = csr->d_hfirst;
   a.fcol = csr->d_fcol;
   a.frow = csr->d_frow;
   a.fval = csr->d_fval;
-  a.xptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
-  a.skip_bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
-  a.add_bias = a.skip_bias;
+  a.fptr = csr->d_fptr;
+  a.add_bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
   a.label = csr->d_label;
   if (csr->hot_dense) {
     a.hmask = csr->d_hmask;
@@ -927,8 +976,7 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
     a.perm = csr->d_perm;
   }
   a.w = csr->d_wsum;
-  a.split = csr->d_fsplit;
-  a.nhot = (uint32_t)std::min<uint64_t>(kFpHot, csr->dim);
+  a.nhot = csr->fp_hot;
   a.shift = csr->d_fp_shift;
   a.nrows = csr->nrows;
   a.panel_rows = csr->fp_rows;
@@ -940,7 +988,7 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
     a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
     a.gscale = std::ldexp(1.0f, csr->fx_shift);
   }
-  const size_t lds = sizeof(unsigned long long) * csr->fp_rows + sizeof(float) * a.nhot;
+  const size_t lds = sizeof(unsigned long long) * csr->fp_rows + sizeof(float) * (a.nhot + 1);
   static bool raised[64] = {};
   if (!raised[ctx->device & 63]) {
     for (const void *fn : {reinterpret_cast<const void *>(&k_forward_rp<FWD_EVAL, true>),
@@ -955,7 +1003,7 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
   const uint64_t npanels = (csr->nrows + csr->fp_rows - 1) / csr->fp_rows;
   const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 2));  // two resident per CU
   *nblocks_out = grid;
-  const bool hasval = a.fval != nullptr;
+  const bool hasval = a.hval != nullptr;
   KernelTimer t(ctx, mode == FWD_EVAL ? ADMM_K_FORWARD_EVAL : ADMM_K_FORWARD);
 #define RP_LAUNCH(M)                                                                                                \
   if (hasval) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_rp<M, true>), dim3(grid), dim3(kRpThreads), lds, ctx->stream, a); \
@@ -1093,7 +1141,8 @@ __device__ inline void t_accumulate(fx_t *acc, fx_t *acc2, uint32_t c, float x, 
 }
 
 // One workgroup per (panel, column block) cell.  The cell's entries are streamed with 16-byte
-// loads (four entries per lane per load); its per-column sums are accumulated with LDS atomics
+// loads (four entries per lane per load; one entry per lane per load, so that adjacent lanes gather
+// adjacent rows, was 12 % slower); its per-column sums are accumulated with LDS atomics
 // while the per-row vector is gathered almost sequentially (a cell keeps its rows nearly in
 // order); the sums are then added to the global per-column vector in one coalesced atomic pass.
 // Workgroups whose index is equal modulo 8 share an XCD under round-robin dispatch; they are
@@ -1194,10 +1243,147 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
   }
 }
 
+// Column stream: the part of X^T r that belongs to the most frequent columns (those outside the row
+// masks).  A workgroup takes panels of kTcRows rows; the panel's slice of the per-row vector sits in
+// LDS, already in fixed point; every lane walks its run of the panel's column-ordered words, sums a
+// column's table entries in a register (exact: integer-valued doubles below 2^51) and adds the sum
+// to the column's LDS accumulator when the column ends -- no memory gather and no atomic per entry.
+// The accumulators go to the global vector once, when the workgroup has swept its panels.
+struct TcArgs {
+  const uint16_t *tw;
+  const float *tv;
+  const uint64_t *tbase;
+  const uint16_t *tfirst;
+  const float *rvec;
+  uint64_t nrows;
+  uint32_t ncols;
+  const uint32_t *perm;  // stored id -> index in g1 (nullptr: identity)
+  unsigned long long *g1;
+  float scale;
+};
+
+template <bool HASVAL>
+__global__ void __launch_bounds__(kTcLanes) k_transposed_cs(TcArgs a) {
+  extern __shared__ fx_t cs_acc[];  // [ncols] column sums, then float rq[2][kTcRows + 1]
+  float *rq = reinterpret_cast<float *>(cs_acc + a.ncols);
+  const int tid = threadIdx.x;
+  const uint64_t npanels = (a.nrows + kTcRows - 1) / kTcRows;
+  const float scale = a.scale;
+  constexpr int kPer = kTcRows / kTcLanes;  // rows of a slice each lane loads
+  for (uint32_t c = tid; c < a.ncols; c += kTcLanes) cs_acc[c] = 0;
+  if (tid < 2) rq[tid * (kTcRows + 1) + kTcRows] = 0.0f;  // the filler words' slot
+  float nxt[kPer];
+  auto fetch = [&](uint64_t p) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const uint64_t r = p * kTcRows + (uint64_t)j * kTcLanes + tid;
+      const float x = r < a.nrows ? a.rvec[r] : 0.0f;
+      nxt[j] = HASVAL ? x : truncf(x * scale);
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) rq[buf * (kTcRows + 1) + j * kTcLanes + tid] = nxt[j];
+  };
+  int buf = 0;
+  if (blockIdx.x < npanels) {
+    fetch(blockIdx.x);
+    put(0);
+  }
+  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+    __syncthreads();  // slice `buf` is complete, and nobody reads the other one any more
+    const bool more = p + gridDim.x < npanels;
+    if (more) fetch(p + gridDim.x);
+    const float *tab = rq + buf * (kTcRows + 1);
+    const uint64_t tb = a.tbase[p];
+    const uint32_t nq = (uint32_t)((a.tbase[p + 1] - tb) / (4 * kTcLanes));
+    uint32_t col = a.tfirst[p * kTcLanes + tid];
+    const u32x2 *src = reinterpret_cast<const u32x2 *>(a.tw + tb) + tid;
+    const f32x4 *vsrc = HASVAL ? reinterpret_cast<const f32x4 *>(a.tv + tb) + tid : nullptr;
+    double sum = 0.0;
+    auto step = [&](uint32_t e, float v) {
+      float x = tab[e & 0x3FFFu];
+      if (HASVAL) x = truncf((x * v) * scale);
+      sum += (double)x;
+      if (e & 0x8000u) {
+        if (sum != 0.0) atomicAdd(&cs_acc[col], rp_d2fx(sum));
+        sum = 0.0;
+        ++col;
+      }
+    };
+    uint32_t q = 0;
+    for (; q + 2 <= nq; q += 2) {
+      const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kTcLanes);
+      const u32x2 c1 = __builtin_nontemporal_load(src + (uint64_t)(q + 1) * kTcLanes);
+      f32x4 v0 = {1.f, 1.f, 1.f, 1.f}, v1 = v0;
+      if (HASVAL) {
+        v0 = __builtin_nontemporal_load(vsrc + (uint64_t)q * kTcLanes);
+        v1 = __builtin_nontemporal_load(vsrc + (uint64_t)(q + 1) * kTcLanes);
+      }
+      step(c0.x & 0xFFFFu, v0.x);
+      step(c0.x >> 16, v0.y);
+      step(c0.y & 0xFFFFu, v0.z);
+      step(c0.y >> 16, v0.w);
+      step(c1.x & 0xFFFFu, v1.x);
+      step(c1.x >> 16, v1.y);
+      step(c1.y & 0xFFFFu, v1.z);
+      step(c1.y >> 16, v1.w);
+    }
+    for (; q < nq; ++q) {
+      const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kTcLanes);
+      f32x4 v0 = {1.f, 1.f, 1.f, 1.f};
+      if (HASVAL) v0 = __builtin_nontemporal_load(vsrc + (uint64_t)q * kTcLanes);
+      step(c0.x & 0xFFFFu, v0.x);
+      step(c0.x >> 16, v0.y);
+      step(c0.y & 0xFFFFu, v0.z);
+      step(c0.y >> 16, v0.w);
+    }
+    if (sum != 0.0) atomicAdd(&cs_acc[col], rp_d2fx(sum));
+    if (more) put(buf ^ 1);
+    buf ^= 1;
+  }
+  __syncthreads();
+  for (uint32_t c = tid; c < a.ncols; c += kTcLanes) {
+    const fx_t v = cs_acc[c];
+    if (v != 0) atomicAdd(&a.g1[a.perm ? a.perm[c] : c], v);
+  }
+}
+
+static int launch_column_stream(admm_csr *csr) {
+  admm_ctx *ctx = csr->ctx;
+  TcArgs a{};
+  a.tw = csr->d_tcw;
+  a.tv = csr->d_tcv;
+  a.tbase = csr->d_tcbase;
+  a.tfirst = csr->d_tcfirst;
+  a.rvec = csr->d_rowbuf;
+  a.nrows = csr->nrows;
+  a.ncols = csr->tc_cols;
+  a.perm = csr->d_perm;
+  a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
+  a.scale = std::ldexp(1.0f, csr->fx_shift);
+  const size_t lds = sizeof(fx_t) * csr->tc_cols + sizeof(float) * 2 * (kTcRows + 1);
+  static bool raised[64] = {};
+  if (!raised[ctx->device & 63]) {
+    for (const void *fn : {reinterpret_cast<const void *>(&k_transposed_cs<true>),
+                           reinterpret_cast<const void *>(&k_transposed_cs<false>)})
+      ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    raised[ctx->device & 63] = true;
+  }
+  const uint64_t npanels = (csr->nrows + kTcRows - 1) / kTcRows;
+  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count));
+  if (a.tv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed_cs<true>), dim3(grid), dim3(kTcLanes), lds, ctx->stream, a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed_cs<false>), dim3(grid), dim3(kTcLanes), lds, ctx->stream, a);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
 int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(csr->has_t, "transposed sweep: call admm_csr_build_transposed first");
   if (p0 >= p1) return ADMM_OK;
+  ADMM_REQUIRE(!csr->has_tc || (!ftrl_mode && p0 == 0 && p1 == csr->npanels),
+               "transposed sweep: a copy with a column stream serves whole-set sweeps only");
   TArgs a{};
   a.tptr = csr->d_tptr;
   a.trow = csr->d_trow;
@@ -1243,6 +1429,7 @@ int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_transposed<false, 512>), dim3(grid), dim3(512), lds, ctx->stream, a);
     ADMM_HIP_CHECK(hipGetLastError());
   }
+  if (csr->has_tc) ADMM_TRY(launch_column_stream(csr));
   return ADMM_OK;
 }
 
@@ -1566,6 +1753,9 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
                       float alpha, float beta, float l1, float l2, uint64_t batch) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(csr->has_t, "admm_ftrl_pass: batch > 1 needs admm_csr_build_transposed");
+  // mini-batches sweep panel ranges, which read cells only: a copy whose frequent columns are in the
+  // column stream is rebuilt without it (once)
+  if (csr->has_tc) ADMM_TRY(build_transposed(csr, csr->panel_rows, csr->col_block, false));
   ADMM_REQUIRE(csr->col_block <= 8192, "admm_ftrl_pass: batch > 1 needs col_block <= 8192 (two accumulators per column)");
   ADMM_REQUIRE(csr->panel_rows == batch || (csr->npanels <= 1 && batch >= csr->nrows),
                "admm_ftrl_pass: batch (%llu) must equal the transposed copy's panel_rows (%llu)",

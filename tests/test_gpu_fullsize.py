@@ -255,3 +255,52 @@ def test_heavy_tailed_rows_over_sixteen_million_features_against_the_oracle():
             v.free()
     dev.destroy()
     ctx.close()
+
+
+@pytest.mark.parametrize("name,rows,dim,draws,kw,nshards", [
+    ("c3", 100_000_000, 1 << 22, 131.0, {}, 8),
+    ("c5", 125_000_000, 1 << 24, 40.0, dict(len_dist=1, tail_sigma=1.2, max_len=1024), 5),
+])
+def test_one_rank_shard_equals_the_sum_of_its_pieces(name, rows, dim, draws, kw, nshards):
+    """The two shapes the benchmark runs, at their full one-GPU size.  Objective and gradient of the
+    whole shard (default layout: row masks, hot stream, column stream, cells) must equal the sums over
+    disjoint row ranges built as separate sets (other panel boundaries, other frequency ranks, larger
+    fixed-point scale), and the gradient must be the derivative of the objective along a direction."""
+    from admm_amd import capi
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 0.05, dim).astype(np.float32)
+    d = rng.normal(0, 1.0, dim).astype(np.float32)
+    d /= np.linalg.norm(d)
+    s = ctx.csr_synth(rows, dim, draws, seed=31, **kw)
+    s.build_transposed(col_block=16384).relabel_by_frequency()
+    nnz = s.nnz
+    dx, g = ctx.vec(dim, x), ctx.vec(dim)
+    f = s.logistic_fg(dx, g, rho=0.0)
+    gw = g.download().astype(np.float64)
+    h = 2e-2
+    fp = s.logistic_fg(ctx.vec(dim, x + np.float32(h) * d), g, rho=0.0)
+    fm = s.logistic_fg(ctx.vec(dim, x - np.float32(h) * d), g, rho=0.0)
+    assert (fp - fm) / (2 * h) == pytest.approx(float(np.dot(gw, d.astype(np.float64))), rel=2e-3, abs=1e-3 * f / rows)
+    # the all-zero point: every residual is +-1/2, the sums of the frequent columns are as large as they get
+    f0 = s.logistic_fg(ctx.vec(dim), g, rho=0.0)
+    g0 = g.download().astype(np.float64)
+    assert f0 == pytest.approx(rows * np.log(2.0), rel=1e-6)
+    s.destroy()
+    fsum, gsum, g0sum, nsum = 0.0, np.zeros(dim), np.zeros(dim), 0
+    per = rows // nshards
+    for k in range(nshards):
+        part = ctx.csr_synth(per, dim, draws, seed=31, row_offset=k * per, **kw)
+        part.build_transposed(col_block=16384).relabel_by_frequency()
+        nsum += part.nnz
+        fsum += part.logistic_fg(dx, g, rho=0.0)
+        gsum += g.download()
+        part.logistic_fg(ctx.vec(dim), g, rho=0.0)
+        g0sum += g.download()
+        part.destroy()
+    assert nsum == nnz
+    assert f == pytest.approx(fsum, rel=1e-9)
+    scale = np.abs(gsum).max()
+    np.testing.assert_allclose(gw, gsum, rtol=1e-6, atol=1e-7 * scale)
+    np.testing.assert_allclose(g0, g0sum, rtol=1e-6, atol=1e-7 * np.abs(g0sum).max())
+    ctx.close()

@@ -12,6 +12,11 @@ export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
   python3 "$root/bench.py" --steps 4 --warmup 1 > "$out/bench_line.json" 2> "$out/bench_stats.err"
 echo "stats done"
+for cfg in c5 ftrl; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$cfg" -o bench -- \
+    python3 "$root/bench.py" --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_${cfg}_line.json" 2> "$out/bench_${cfg}_stats.err"
+  echo "stats $cfg done"
+done
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o pmc -- \
   python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_fetch_line.json" 2> "$out/pmc_fetch.err"
 echo "fetch done"
