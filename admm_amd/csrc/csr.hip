@@ -530,6 +530,25 @@ __global__ void __launch_bounds__(kFpBuildThreads) k_fpsort(FpBuildArgs a) {
   }
 }
 
+// Bit transpose of the first mask word in tiles of 64 rows: out[64 t + c] bit k = in[64 t + k] bit c.
+// One wavefront per tile; rows past the end count as empty.
+__global__ void __launch_bounds__(256) k_mask_transpose(const uint64_t *__restrict__ hmask, uint64_t nrows,
+                                                        uint64_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t ntiles = (nrows + 63) / 64;
+  const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+  for (uint64_t t = wave; t < ntiles; t += nwaves) {
+    const uint64_t r = t * 64 + lane;
+    const unsigned long long m = r < nrows ? hmask[r] : 0ull;
+    unsigned long long mine = 0;
+    for (int c = 0; c < 64; ++c) {
+      const unsigned long long b = __ballot((m >> c) & 1ull);
+      if (lane == c) mine = b;
+    }
+    out[t * 64 + lane] = mine;
+  }
+}
+
 // ---- hot stream of the row-panel copy ---------------------------------------------------------
 
 struct HpBuildArgs {
@@ -890,7 +909,8 @@ __global__ void __launch_bounds__(256) k_maxrowlen(const uint64_t *__restrict__ 
 int build_forward_panels(admm_csr *csr) {
   admm_ctx *ctx = csr->ctx;
   for (void **p : {(void **)&csr->d_fcol, (void **)&csr->d_frow, (void **)&csr->d_fval, (void **)&csr->d_fptr,
-                   (void **)&csr->d_hcol, (void **)&csr->d_hval, (void **)&csr->d_hbase, (void **)&csr->d_hfirst}) {
+                   (void **)&csr->d_hcol, (void **)&csr->d_hval, (void **)&csr->d_hbase, (void **)&csr->d_hfirst,
+                   (void **)&csr->d_hmaskT}) {
     if (*p) hipFree(*p);
     *p = nullptr;
   }
@@ -968,6 +988,13 @@ int build_forward_panels(admm_csr *csr) {
       ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(sizeof(uint32_t) * (kFpMaxBins + kFpBuildThreads))));
     raised[ctx->device & 63] = true;
+  }
+  if (csr->hot_dense) {  // the first mask word by column, for the sweep's column sums
+    const uint64_t ntiles = (csr->nrows + 63) / 64;
+    ADMM_HIP_CHECK(hipMalloc(&csr->d_hmaskT, sizeof(uint64_t) * ntiles * 64));
+    hipLaunchKernelGGL(k_mask_transpose, dim3(grid_for(ntiles * 64, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream,
+                       csr->d_hmask, csr->nrows, csr->d_hmaskT);
+    ADMM_HIP_CHECK(hipGetLastError());
   }
   // ---- hot stream
   h.hlen = h.clen = nullptr;
@@ -1050,7 +1077,7 @@ static void free_csr(admm_csr *c) {
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol,
                   c->d_fcol,   c->d_frow, c->d_fval, c->d_fp_shift, c->d_fptr, c->d_hcol, c->d_hval, c->d_hbase, c->d_hfirst,
-                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst};
+                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst, c->d_hmaskT};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;
@@ -1188,7 +1215,7 @@ extern "C" int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]) {
   const uint64_t n = csr->nrows;
   out[0] = 8 * (n + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * n;
   if (csr->has_fp)  // row-panel copy: masks + hot stream (u16 [, value]) + (column u32, row u16 [, value]) per remaining entry + labels
-    out[1] = (csr->hot_dense ? 8 * n * (1 + kWarmWords) : 0) + (csr->d_hval ? 6 : 2) * csr->hp_words +
+    out[1] = (csr->hot_dense ? 8 * n * (2 + kWarmWords) : 0) + (csr->d_hval ? 6 : 2) * csr->hp_words +
              (csr->d_fval ? 10 : 6) * csr->fp_nnz + 4 * n;
   else
     out[1] = csr->hot_dense ? 8 * (n + 1) + 8 * n * (1 + kWarmWords) + 4 * csr->cnnz + (csr->d_cval ? 4 * csr->cnnz : 0) + 4 * n

@@ -116,6 +116,8 @@ struct admm_csr {
   // its unit-valued entries in the 64 most frequent columns, and the remaining entries as CSR
   bool hot_dense = false;
   uint64_t *d_hmask = nullptr, *d_hwarm = nullptr, *d_crowptr = nullptr;
+  // d_hmask transposed in tiles of 64 rows: word 64 t + c holds, for rows 64 t .. 64 t + 63, who stores column c
+  uint64_t *d_hmaskT = nullptr;
   uint32_t *d_ccol = nullptr;
   float *d_cval = nullptr;
   uint64_t cnnz = 0;

@@ -43,6 +43,7 @@ struct FwdArgs {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline float clamp35(float m) { return fmaxf(fminf(m, 35.0f), -35.0f); }
 
@@ -625,6 +626,7 @@ struct RpArgs {
   const uint64_t *fptr;    // per panel: first of those entries
   const float *label;
   const uint64_t *hmask, *hwarm;  // nullptr: no mask tier
+  const uint64_t *hmaskT;  // hmask bit-transposed in tiles of 64 rows
   const uint32_t *perm;    // stored id -> caller's id (relabelled sets), for the column sums' destination
   uint32_t nhot;           // leading entries of w cached in LDS
   const float *w;          // gathered vector in the set's stored column order
@@ -684,12 +686,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   }
   const float w0 = a.add_bias ? a.w[0] : 0.0f;
   double acc0 = 0, acc1 = 0;
-  unsigned long long h1 = 0;  // lane k: X^T r of mask column k over the rows this wave has seen
-  auto bcast = [](unsigned long long v, int src) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
-    return ((unsigned long long)hi << 32) | lo;
-  };
+  i32x4 cacc[4] = {};  // column sums of the first mask word, by digit (see the epilogue)
   __syncthreads();
   for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
     const uint64_t r0 = p * R;
@@ -819,23 +816,36 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         }
       }
       if (colsums) {
-        // X^T r of the mask columns over these 64 rows: the dense word by broadcast + inverse ballot
-        // (lane k <-> column k), the sparse words by walking each row's set bits into LDS accumulators
-        // (the same sums by broadcast and ballot for all four words were slower: 1.90 against 1.64 ms
-        // per 10M rows)
-        const unsigned long long m0 = on ? a.hmask[r0 + r] : 0ull;
+        // X^T r of the mask columns over these 64 rows.  First word (64 columns, about half of a row's
+        // entries): a 64 x 64 bit matrix times the residuals on the matrix unit.  The residuals, offset
+        // to be positive, are cut into six 7-bit digits plus a constant 1 (which counts a column's rows,
+        // to take the offset out again); D[column][digit] += sum over rows of bit * digit, in i32,
+        // exact.  The digits are handed over through the wave's own 64 margins in LDS, which it has
+        // read.  Other words: each row's set bits walked into LDS accumulators (the same sums by
+        // broadcast and ballot for all four words were slower: 1.90 against 1.64 ms per 10M rows).
+        {
+          const unsigned long long u = rv + (1ull << 41);  // |rv| <= 2^37
+          unsigned char *pl = reinterpret_cast<unsigned char *>(rp_acc + rb);
+#pragma unroll
+          for (int n = 0; n < 6; ++n) pl[n * 64 + lane] = (unsigned char)((u >> (7 * n)) & 127u);
+          pl[6 * 64 + lane] = 1;
+          i32x4 bfrag = {0, 0, 0, 0};
+          if ((lane & 15) < 7) bfrag = *reinterpret_cast<const i32x4 *>(pl + (lane & 15) * 64 + 16 * (lane >> 4));
+          const uint16_t *tt = reinterpret_cast<const uint16_t *>(a.hmaskT + (r0 + rb));
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const uint32_t bits = tt[(16 * m + (lane & 15)) * 4 + (lane >> 4)];  // column 16 m + (lane & 15), rows 16 (lane >> 4) ..
+            i32x4 afrag;
+            afrag.x = (int)((((bits >> 0) & 15u) * 0x204081u) & 0x01010101u);
+            afrag.y = (int)((((bits >> 4) & 15u) * 0x204081u) & 0x01010101u);
+            afrag.z = (int)((((bits >> 8) & 15u) * 0x204081u) & 0x01010101u);
+            afrag.w = (int)((((bits >> 12) & 15u) * 0x204081u) & 0x01010101u);
+            cacc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag, bfrag, cacc[m], 0, 0, 0);
+          }
+        }
         unsigned long long mw[kWarmWords];
 #pragma unroll
         for (int w = 0; w < kWarmWords; ++w) mw[w] = on ? a.hwarm[(r0 + r) * kWarmWords + w] : 0ull;
-        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll 4
-        for (int kk = 0; kk < 64; kk += 4) {
-          p0 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk)) ? bcast(rv, kk) : 0ull;
-          p1 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk + 1)) ? bcast(rv, kk + 1) : 0ull;
-          p2 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk + 2)) ? bcast(rv, kk + 2) : 0ull;
-          p3 += __builtin_amdgcn_inverse_ballot_w64(bcast(m0, kk + 3)) ? bcast(rv, kk + 3) : 0ull;
-        }
-        h1 += (p0 + p1) + (p2 + p3);
         while (mw[0] | mw[1] | mw[2]) {
 #pragma unroll
           for (int w = 0; w < kWarmWords; ++w) {
@@ -851,7 +861,20 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   }
   static_assert(kWarmWords == 3, "the walk above names three words");
   if (colsums) {
-    if (h1) atomicAdd(&wacc[lane], h1);
+    // D of block m: this lane holds column 16 m + 4 (lane >> 4) + i, digit lane & 15, in element i
+    const int digit = lane & 15;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long v = cacc[m][i];
+        const int col = 16 * m + 4 * (lane >> 4) + i;
+        if (digit < 6) {
+          if (v) atomicAdd(&wacc[col], (unsigned long long)(v << (7 * digit)));
+        } else if (digit == 6) {
+          if (v) atomicAdd(&wacc[col], (unsigned long long)(-(v << 41)));
+        }
+      }
     __syncthreads();
     if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.g1 + a.perm[tid], wacc[tid]);
   }
@@ -973,6 +996,7 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
   if (csr->hot_dense) {
     a.hmask = csr->d_hmask;
     a.hwarm = csr->d_hwarm;
+    a.hmaskT = csr->d_hmaskT;
     a.perm = csr->d_perm;
   }
   a.w = csr->d_wsum;
