@@ -19,7 +19,7 @@ SYMBOLS = [
     "admm_vec_alloc", "admm_vec_free", "admm_vec_zero", "admm_vec_copy", "admm_vec_upload",
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
-    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_layout_bytes",
+    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_layout_bytes", "admm_csr_layout_counts",
     "admm_csr_destroy",
     "admm_predict", "admm_metrics", "admm_auc_scores", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus", "admm_consensus_static",
@@ -88,6 +88,7 @@ def load():
         "admm_csr_relabel_by_frequency": [vp],
         "admm_csr_bytes": [vp, C.POINTER(u64), C.POINTER(u64)],
         "admm_csr_layout_bytes": [vp, C.POINTER(u64)],
+        "admm_csr_layout_counts": [vp, C.POINTER(u64)],
         "admm_csr_destroy": [vp],
         "admm_predict": [vp, C.POINTER(vp), i32, vp],
         "admm_metrics": [vp, C.POINTER(vp), i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -339,6 +340,13 @@ class SampleSet:
         out = (C.c_uint64 * 4)()
         _check(self.ctx.L.admm_csr_layout_bytes(self.h, out))
         return dict(zip(("row_major", "forward_form", "column_block_copy", "row_vectors"), [int(v) for v in out]))
+
+    def layout_counts(self):
+        """dict of entry counts by layout (admm_csr_layout_counts)"""
+        out = (C.c_uint64 * 6)()
+        _check(self.ctx.L.admm_csr_layout_counts(self.h, out))
+        return dict(zip(("mask_entries", "hot_stream_words", "list_entries", "column_stream_words", "cell_entries",
+                         "cells"), [int(v) for v in out]))
 
     def _groups(self, groups):
         arr = (C.c_void_p * len(groups))(*[g.ptr.value for g in groups])

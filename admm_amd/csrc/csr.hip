@@ -1227,6 +1227,17 @@ extern "C" int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]) {
   return ADMM_OK;
 }
 
+extern "C" int admm_csr_layout_counts(const admm_csr *csr, uint64_t out[6]) {
+  ADMM_REQUIRE(csr && out, "admm_csr_layout_counts: NULL argument");
+  out[0] = csr->hot_dense ? csr->nnz - csr->cnnz : 0;
+  out[1] = csr->has_fp ? csr->hp_words : 0;
+  out[2] = csr->has_fp ? csr->fp_nnz : 0;
+  out[3] = csr->has_tc ? csr->tc_words : 0;
+  out[4] = csr->has_t ? csr->tnnz : 0;
+  out[5] = csr->has_t ? csr->npanels * csr->nblocks : 0;
+  return ADMM_OK;
+}
+
 extern "C" int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, float *val,
                                  float *label) {
   ADMM_REQUIRE(csr, "admm_csr_download: csr is NULL");

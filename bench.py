@@ -281,6 +281,8 @@ def pmc_traffic(args, world, rows_total, sym):
     if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus"), bool(wl.get("explicit_values"))) != \
             (rows_total, args.dim, world, args.explicit_values):
         return None, None
+    if sym == "k_transposed<false" and "transposed_sweep_total" in pmc:   # cells + column stream: one sweep
+        return pmc["transposed_sweep_total"]["traffic_bytes"], "profiles/pmc_traffic_%s.json" % args.config
     for name, rec in pmc["kernels"].items():
         if sym in name:
             return rec["traffic_bytes"], "profiles/pmc_traffic_%s.json" % args.config
@@ -442,7 +444,7 @@ def run_admm(args):
         kernels = sweep_kernels(train, rows, args.dim, fwd_ms, fwd_n, tr_ms, tr_n)
         dom = "transposed_block_sweep" if tr_ms >= fwd_ms else "forward_csr_sweep"
         traffic, traffic_src = pmc_traffic(args, world, rows_total,
-                                           "k_transposed<false" if dom == "transposed_block_sweep" else "k_forward<1")
+                                           "k_transposed<false" if dom == "transposed_block_sweep" else "k_forward_rp<1")
         out = {
             "metric": METRIC,
             "value": swept / dt,
@@ -477,6 +479,7 @@ def run_admm(args):
                 "global_test_metrics": {"logloss": g_loss, "auc": g_auc, "rows": g_rows},
                 "generate_and_build_s": t_gen,
                 "rank0_hbm_bytes": train.layout_bytes(),
+                "rank0_layout_counts": train.layout_counts(),
                 "last_line": driver.format_line("rank0", *last_rec["line"]) if last_rec and last_rec["line"] else None,
                 "last_residuals_rank0": [last_rec["r2"], last_rec["s2"]] if last_rec else None,
                 "last_residuals_all_ranks": global_res,

@@ -123,6 +123,11 @@ int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t *transpose
  * as CSR + labels; else the CSR itself), out[2] the column-block copy the transposed sweep streams,
  * out[3] the per-row work vectors allocated so far. */
 int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]);
+/* Entry counts behind those layouts (what a bytes-moved estimate is built from): out[0] entries held
+ * as bits of the row masks, out[1] 16-bit words of the forward sweep's hot stream, out[2] entries of
+ * its (column, row) lists, out[3] 16-bit words of the transposed sweep's column stream, out[4] entries
+ * of the column-block cells, out[5] cells.  No counterpart in the reference. */
+int admm_csr_layout_counts(const admm_csr *csr, uint64_t out[6]);
 int admm_csr_destroy(admm_csr *csr);
 
 /* ---- metrics (Metrics, src/metrics.cc:45-117) --------------------------------------------- */

@@ -1,16 +1,18 @@
-"""Per-launch HBM traffic of the two sweeps from two rocprofv3 counter passes (FETCH_SIZE and
-WRITE_SIZE, one pass each) over `bench.py --steps 1 --warmup 0 --no-cpu-baseline`.
+"""Per-launch HBM-side traffic of the sweep kernels from two rocprofv3 counter passes (FETCH_SIZE and
+WRITE_SIZE, one pass each) over `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch`,
+corrected with the calibration of tools/fetch_size_calib.hip.
 
-    python tools/pmc_traffic.py FETCH.csv WRITE.csv BENCH_LINE.json OUT.json [--tcol-factor F]
+    python tools/pmc_traffic.py FETCH.csv WRITE.csv BENCH_LINE.json CALIB.csv OUT.json
 
-Counter values are KB per dispatch.  On gfx950 FETCH_SIZE tallies a coalesced streaming read that
-asks for whole 128-byte lines (16 bytes per lane, or a wave-wide run of consecutive dwords: the
-forward sweep's raw count did not move when its stream went from the first form to the second) at
-half its bytes, so the bytes a kernel streams that way are added once more; the factor for
-the 8-byte-per-lane stream of the column-block copy's column field is measured separately (a run of
-the transposed sweep with its gathers switched off, whose bytes are known) and passed in.
-"""
-import argparse
+Counter values are KB per dispatch.  On gfx950 FETCH_SIZE tallies a coalesced streaming read at a
+fixed fraction of its bytes that depends on the bytes per lane (the calibration program reads 1 GiB
+with 2, 4, 8 and 16 bytes per lane: one half for 4, 8 and 16, next to nothing for 2); a scattered
+4-byte gather that leaves the L2 is tallied as the 64-byte request it is.  So for every kernel
+
+    traffic = FETCH_SIZE + sum over its streams of (1 - factor(width)) * bytes(stream) + WRITE_SIZE
+
+with the streams' bytes taken from the entry counts of the layouts (config.rank0_layout_counts).
+What is left of FETCH_SIZE after the streams' own share is the gathers' (and the small vectors')."""
 import csv
 import json
 import sys
@@ -27,49 +29,70 @@ def per_kernel(path, counter):
     return {k: (tot[k] / cnt[k] * 1024.0, cnt[k]) for k in tot}
 
 
+def calibration(path):
+    got = per_kernel(path, "FETCH_SIZE")
+    out = {}
+    for name, (b, _) in got.items():
+        for key, width in (("unsigned short", 2), ("unsigned int __vector(2)", 8), ("unsigned int __vector(4)", 16),
+                           ("unsigned int>", 4)):
+            if "k_read<" + key in name:
+                out[width] = b / float(1 << 30)
+                break
+    return out
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("fetch_csv")
-    ap.add_argument("write_csv")
-    ap.add_argument("bench_line")
-    ap.add_argument("out")
-    ap.add_argument("--tcol-factor", type=float, default=1.0,
-                    help="fraction of the 8-byte-per-lane column-field stream that FETCH_SIZE reports")
-    args = ap.parse_args()
-    line = json.loads(open(args.bench_line).read().strip().splitlines()[-1])
+    fetch_csv, write_csv, bench_line, calib_csv, out_path = sys.argv[1:6]
+    line = json.loads(open(bench_line).read().strip().splitlines()[-1])
     cfg = line["config"]
-    explicit = "stored as f32" in cfg.get("values", "stored as f32")
-    hb = cfg["rank0_hbm_bytes"]
-    per_entry_copy = 10 if explicit else 6
-    copied = hb["column_block_copy"] / per_entry_copy       # entries not held by the row masks (approx.)
-    fetch = per_kernel(args.fetch_csv, "FETCH_SIZE")
-    write = per_kernel(args.write_csv, "WRITE_SIZE")
+    explicit = "stored as f32" in cfg.get("values", "")
+    cnt = cfg["rank0_layout_counts"]
+    rows = cfg["rows_total"] // line["n_gpus"]
+    factor = calibration(calib_csv)
+    fetch = per_kernel(fetch_csv, "FETCH_SIZE")
+    write = per_kernel(write_csv, "WRITE_SIZE")
     kern = line["roofline"]["kernels"]
-    out = {
-        "about": __doc__.strip(),
-        "workload": {"rows_total": cfg["rows_total"], "dim": cfg["dim"], "n_gpus": line["n_gpus"],
-                     "explicit_values": explicit},
-        "tcol_factor": args.tcol_factor,
-        "kernels": {},
+    hp, lst, tcw, cell = cnt["hot_stream_words"], cnt["list_entries"], cnt["column_stream_words"], cnt["cell_entries"]
+    masked = cnt["mask_entries"] > 0
+    # streams per kernel: (bytes per lane of the load instruction, bytes per launch)
+    streams = {
+        "k_forward_rp<1": [(8, 2.0 * hp), (4, 4.0 * lst), (2, 2.0 * lst), (8, 32.0 * rows if masked else 0.0), (4, 4.0 * rows)]
+                          + ([(16, 4.0 * hp), (4, 4.0 * lst)] if explicit else []),
+        "k_transposed<false": [(16, 4.0 * cell), (8, 2.0 * cell)] + ([(16, 4.0 * cell)] if explicit else []),
+        "k_transposed_cs<": [(8, 2.0 * tcw), (4, 4.0 * rows)] + ([(16, 4.0 * tcw)] if explicit else []),
     }
+    alg = {"k_forward_rp<1": kern["forward_csr_sweep"]["algorithmic_bytes"],
+           "k_transposed<false": kern["transposed_block_sweep"]["algorithmic_bytes"],
+           "k_transposed_cs<": None}
+    out = {"about": __doc__.strip(), "fetch_size_factor_by_bytes_per_lane": factor,
+           "workload": {"rows_total": cfg["rows_total"], "dim": cfg["dim"], "n_gpus": line["n_gpus"],
+                        "explicit_values": explicit, "layout_counts": cnt},
+           "kernels": {}}
     for name, (fbytes, n) in fetch.items():
-        if "k_forward<1" in name:
-            s16 = copied * (8 if explicit else 4)            # col (+ val) of the compact row-major form
-            s8, alg = 0.0, kern["forward_csr_sweep"]["algorithmic_bytes"]
-        elif "k_transposed<false" in name:
-            s16 = copied * (8 if explicit else 4)            # row (+ val) fields, 16 bytes per lane
-            s8, alg = copied * 2, kern["transposed_block_sweep"]["algorithmic_bytes"]
-        else:
-            continue
-        w = write.get(name, (0.0, 0))[0]
-        traffic = fbytes + s16 / 2 + s8 * (1.0 - args.tcol_factor) + w
-        out["kernels"][name] = {
-            "launches_profiled": n, "FETCH_SIZE_bytes_raw": fbytes, "WRITE_SIZE_bytes": w,
-            "streamed_16B_bytes": s16, "streamed_8B_bytes": s8, "traffic_bytes": traffic,
-            "algorithmic_bytes": alg, "traffic_over_algorithmic": traffic / alg,
-        }
-    json.dump(out, open(args.out, "w"), indent=1)
-    print(json.dumps(out["kernels"], indent=1))
+        for key, ss in streams.items():
+            if key in name:
+                w = write.get(name, (0.0, 0))[0]
+                stream_bytes = sum(b for _, b in ss)
+                uncounted = sum((1.0 - factor.get(width, 0.5)) * b for width, b in ss)
+                traffic = fbytes + uncounted + w
+                out["kernels"][name] = {
+                    "launches_profiled": n, "FETCH_SIZE_bytes_raw": fbytes, "WRITE_SIZE_bytes": w,
+                    "streamed_bytes": stream_bytes, "streamed_bytes_not_in_FETCH_SIZE": uncounted,
+                    "gather_and_vector_bytes": fbytes - (stream_bytes - uncounted),
+                    "traffic_bytes": traffic, "algorithmic_bytes": alg[key],
+                    "traffic_over_algorithmic": traffic / alg[key] if alg[key] else None,
+                }
+    k = out["kernels"]
+    cs = [v for n, v in k.items() if "k_transposed_cs<" in n]
+    cells = [v for n, v in k.items() if "k_transposed<false" in n]
+    if cs and cells:
+        total = cs[0]["traffic_bytes"] + cells[0]["traffic_bytes"]
+        out["transposed_sweep_total"] = {"traffic_bytes": total, "algorithmic_bytes": cells[0]["algorithmic_bytes"],
+                                         "traffic_over_algorithmic": total / cells[0]["algorithmic_bytes"]}
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps({n[:40]: {a: b for a, b in v.items() if a in ("traffic_bytes", "traffic_over_algorithmic",
+                                                                   "gather_and_vector_bytes")}
+                      for n, v in k.items()}, indent=1))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one round on the GPU box into gpurun_out/prof_<tag>/:
-# kernel statistics of the default bench run, and separate FETCH_SIZE / WRITE_SIZE counter passes.
+# kernel statistics of the three bench configurations, separate FETCH_SIZE / WRITE_SIZE counter
+# passes over one step of the default configuration, and the calibration of FETCH_SIZE for 2-, 4-,
+# 8- and 16-byte-per-lane streaming reads (tools/fetch_size_calib.hip, built beforehand).
 #   tools/profile_round.sh <tag>
 set -e -o pipefail
 tag=${1:-rX}
@@ -17,14 +19,16 @@ for cfg in c5 ftrl; do
     python3 "$root/bench.py" --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_${cfg}_line.json" 2> "$out/bench_${cfg}_stats.err"
   echo "stats $cfg done"
 done
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_explicit" -o bench -- \
+  python3 "$root/bench.py" --explicit-values --rows 50000000 --steps 2 --warmup 1 --no-cpu-baseline --no-other-linesearch > "$out/bench_explicit_line.json" 2> "$out/bench_explicit_stats.err"
+echo "stats explicit done"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o pmc -- \
   python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_fetch_line.json" 2> "$out/pmc_fetch.err"
 echo "fetch done"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o pmc -- \
   python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_write_line.json" 2> "$out/pmc_write.err"
 echo "write done"
-# calibration of the 8-byte-per-lane stream: transposed sweep with its gathers switched off
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o pmc -- \
-  python3 "$root/tools/sweep_bench.py" --no-gather > "$out/calib_line.txt" 2> "$out/calib.err"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o pmc -- \
+  "$root/tools/fetch_size_calib" > "$out/calib_line.txt" 2> "$out/calib.err"
 echo "calibration done"
-find "$out" -name "*.csv" | head -20
+find "$out" -name "*.csv" | head -40
