@@ -60,40 +60,45 @@ __global__ void __launch_bounds__(256) k_auc_sum(const uint32_t *__restrict__ st
 
 int auc_scores(admm_ctx *ctx, const float *labels, const float *scores, uint64_t n, double *auc_out) {
   ADMM_REQUIRE(n < 0x7FFFFFFFull, "admm_metrics: AUC supports up to 2^31-1 rows");
-  float *keys = nullptr;
-  uint32_t *flag_in = nullptr, *flag_out = nullptr, *start = nullptr;
-  void *tmp = nullptr;
-  auto cleanup = [&]() {
-    for (void *p : {(void *)keys, (void *)flag_in, (void *)flag_out, (void *)start, tmp})
-      if (p) hipFree(p);
-  };
+  // one workspace kept in the context: four n-element arrays and the sort's scratch
+  const size_t arr = (sizeof(uint32_t) * n + 255) & ~(size_t)255;
+  size_t bytes = 0, bytes2 = 0;
 #define AUC_CHECK(expr)                                                        \
   do {                                                                         \
     hipError_t e_ = (expr);                                                    \
     if (e_ != hipSuccess) {                                                    \
       set_error("admm_metrics(auc): %s: %s", #expr, hipGetErrorString(e_));    \
-      cleanup();                                                               \
       return e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;        \
     }                                                                          \
   } while (0)
-  AUC_CHECK(hipMalloc(&keys, sizeof(float) * n));
-  AUC_CHECK(hipMalloc(&flag_in, sizeof(uint32_t) * n));
-  AUC_CHECK(hipMalloc(&flag_out, sizeof(uint32_t) * n));
-  AUC_CHECK(hipMalloc(&start, sizeof(uint32_t) * n));
+  AUC_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, scores, (float *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                      (size_t)n, 0, 32, ctx->stream));
+  AUC_CHECK(rocprim::inclusive_scan(nullptr, bytes2, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n,
+                                    rocprim::maximum<uint32_t>(), ctx->stream));
+  if (bytes2 > bytes) bytes = bytes2;
+  if (bytes < 16) bytes = 16;
+  const size_t need = 4 * arr + bytes;
+  if (ctx->auc_ws_bytes < need) {
+    AUC_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->auc_ws) AUC_CHECK(hipFree(ctx->auc_ws));
+    ctx->auc_ws = nullptr;
+    ctx->auc_ws_bytes = 0;
+    AUC_CHECK(hipMalloc(&ctx->auc_ws, need));
+    ctx->auc_ws_bytes = need;
+  }
+  char *base = static_cast<char *>(ctx->auc_ws);
+  float *keys = reinterpret_cast<float *>(base);
+  uint32_t *flag_in = reinterpret_cast<uint32_t *>(base + arr), *flag_out = reinterpret_cast<uint32_t *>(base + 2 * arr),
+           *start = reinterpret_cast<uint32_t *>(base + 3 * arr);
+  void *tmp = base + 4 * arr;
   const int grid = grid_for(n, 256, ctx->cu_count * 8);
   hipLaunchKernelGGL(k_auc_flags, dim3(grid), dim3(256), 0, ctx->stream, labels, flag_in, n);
-  size_t bytes = 0, bytes2 = 0;
-  AUC_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, scores, keys, flag_in, flag_out, (size_t)n, 0, 32, ctx->stream));
-  AUC_CHECK(rocprim::inclusive_scan(nullptr, bytes2, start, start, (size_t)n, rocprim::maximum<uint32_t>(), ctx->stream));
-  if (bytes2 > bytes) bytes = bytes2;
-  AUC_CHECK(hipMalloc(&tmp, bytes ? bytes : 16));
   AUC_CHECK(rocprim::radix_sort_pairs(tmp, bytes, scores, keys, flag_in, flag_out, (size_t)n, 0, 32, ctx->stream));
   hipLaunchKernelGGL(k_auc_heads, dim3(grid), dim3(256), 0, ctx->stream, keys, start, n);
   AUC_CHECK(rocprim::inclusive_scan(tmp, bytes, start, start, (size_t)n, rocprim::maximum<uint32_t>(), ctx->stream));
   hipLaunchKernelGGL(k_auc_sum, dim3(grid), dim3(256), 0, ctx->stream, start, flag_out, n, ctx->d_partials);
   AUC_CHECK(hipGetLastError());
   int rc = finish_partials(ctx, 2, grid);
-  cleanup();
 #undef AUC_CHECK
   if (rc != ADMM_OK) return rc;
   const double rank_sum = ctx->h_scalars[0], P = ctx->h_scalars[1], N = (double)n - P;

@@ -386,6 +386,8 @@ extern "C" int admm_ctx_destroy(admm_ctx *ctx) {
   if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
   if (ctx->lbfgs_ws) hipFree(ctx->lbfgs_ws);
   if (ctx->d_multi) hipFree(ctx->d_multi);
+  if (ctx->auc_ws) hipFree(ctx->auc_ws);
+  if (ctx->d_lb) hipFree(ctx->d_lb);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return ADMM_OK;

@@ -83,6 +83,11 @@ struct admm_ctx {
   // L-BFGS workspace (lazily sized)
   float *lbfgs_ws = nullptr;
   uint64_t lbfgs_ws_floats = 0;
+  // AUC workspace (sort keys, flags, rank starts, the sort's own scratch); grows, never shrinks
+  void *auc_ws = nullptr;
+  size_t auc_ws_bytes = 0;
+  // device scalars of the L-BFGS two-loop recursion (see admm_lbfgs_solve)
+  double *d_lb = nullptr;
   // argument table of a multi-pass FTRL launch
   void *d_multi = nullptr;
   size_t multi_bytes = 0;

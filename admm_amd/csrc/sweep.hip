@@ -1497,8 +1497,10 @@ __global__ void __launch_bounds__(256) k_fg_finish(long long *__restrict__ accum
   if (threadIdx.x == 0) partials[2 * kMaxPartialBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ void __launch_bounds__(256) k_finish_row(const double *partials, int row, int nblocks, double *scalars) {
+// block b sums partial row first + b
+__global__ void __launch_bounds__(256) k_finish_row(const double *partials, int first, int nblocks, double *scalars) {
   __shared__ double sh[256];
+  const int row = first + blockIdx.x;
   double acc = 0;
   for (int i = threadIdx.x; i < nblocks; i += 256) acc += partials[(size_t)row * kMaxPartialBlocks + i];
   sh[threadIdx.x] = acc;
@@ -1511,10 +1513,9 @@ __global__ void __launch_bounds__(256) k_finish_row(const double *partials, int 
 }
 
 static int reduce_rows(admm_ctx *ctx, int first, int count, int nblocks) {
-  for (int r = first; r < first + count; ++r) {
-    hipLaunchKernelGGL(k_finish_row, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, r, nblocks, ctx->d_scalars);
-    ADMM_HIP_CHECK(hipGetLastError());
-  }
+  if (count <= 0) return ADMM_OK;
+  hipLaunchKernelGGL(k_finish_row, dim3(count), dim3(256), 0, ctx->stream, ctx->d_partials, first, nblocks, ctx->d_scalars);
+  ADMM_HIP_CHECK(hipGetLastError());
   return ADMM_OK;
 }
 
@@ -1522,6 +1523,54 @@ static int fetch_scalars(admm_ctx *ctx, int count) {
   ADMM_HIP_CHECK(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return ADMM_OK;
+}
+
+// dot products without a host round trip each: `count` (at most 4) pairs go to partial rows 3.. and
+// d_scalars[3..]; the caller fetches once
+struct DotReq {
+  const float *a, *b;
+};
+
+__global__ void __launch_bounds__(256) k_dot_row(const float *__restrict__ a, const float *__restrict__ b, uint64_t n,
+                                                 double *__restrict__ partials) {
+  __shared__ double sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += (double)a[i] * (double)b[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+static int dots_async(admm_ctx *ctx, const DotReq *req, int count, uint64_t n) {
+  const int grid = grid_for(n, 256, ctx->cu_count * 8);
+  for (int i = 0; i < count; ++i) {
+    hipLaunchKernelGGL(k_dot_row, dim3(grid), dim3(256), 0, ctx->stream, req[i].a, req[i].b, n,
+                       ctx->d_partials + (size_t)(3 + i) * kMaxPartialBlocks);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  return reduce_rows(ctx, 3, count, grid);
+}
+
+static int dots(admm_ctx *ctx, const DotReq *req, int count, uint64_t n, double *out) {
+  ADMM_TRY(dots_async(ctx, req, count, n));
+  ADMM_TRY(fetch_scalars(ctx, 3 + count));
+  for (int i = 0; i < count; ++i) out[i] = ctx->h_scalars[3 + i];
+  return ADMM_OK;
+}
+
+// One step of the two-loop recursion with its coefficient computed on the device from the dot
+// product the stream has just reduced (*num): mode 0: alpha = *num / den is stored and y -= alpha x;
+// mode 1: y += (*alpha - *num / den) x.  Same double arithmetic and float rounding as on the host.
+__global__ void __launch_bounds__(256) k_axpy_coef(float *__restrict__ y, const float *__restrict__ x, uint64_t n,
+                                                   const double *__restrict__ num, double den, double *__restrict__ alpha,
+                                                   int mode) {
+  const double q = *num / den;
+  const float a = mode == 0 ? (float)(-q) : (float)(*alpha - q);
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+  if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) *alpha = q;
 }
 
 // number of positions where two vectors (and, when given, two more) differ bit for bit
@@ -1666,7 +1715,8 @@ __global__ void __launch_bounds__(256) k_mask_colsums(const unsigned long long *
 
 static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const float *z, const float *ydual,
                        float rho, double *f_out, float *g_out, double *loss_out = nullptr,
-                       float *margins_out = nullptr, float *gl_out = nullptr) {
+                       float *margins_out = nullptr, float *gl_out = nullptr, const float *dot_with = nullptr,
+                       double *dot_out = nullptr) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(csr->has_t, "admm_logistic_fg: call admm_csr_build_transposed first");
   ADMM_TRY(ensure_rowbuf(csr));
@@ -1684,10 +1734,15 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
     ADMM_HIP_CHECK(hipGetLastError());
   }
   ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
+  if (dot_with) {  // g . dot_with rides on the same fetch
+    const DotReq rq = {g_out, dot_with};
+    ADMM_TRY(dots_async(ctx, &rq, 1, csr->dim));
+  }
   if (f_out) {
-    ADMM_TRY(fetch_scalars(ctx, 3));
+    ADMM_TRY(fetch_scalars(ctx, dot_with ? 4 : 3));
     *f_out = ctx->h_scalars[0] + ctx->h_scalars[2];
     if (loss_out) *loss_out = ctx->h_scalars[0];
+    if (dot_with && dot_out) *dot_out = ctx->h_scalars[3];
   }
   return ADMM_OK;
 }
@@ -1887,7 +1942,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   float *g = ctx->lbfgs_ws, *xp = g + dim, *gp = xp + dim, *d = gp + dim;
   float *s_new = d + dim, *y_new = s_new + dim;  // the newest pair, before it is known to be usable
   float *S = y_new + dim, *Y = S + (uint64_t)P.m * dim;
-  std::vector<double> ys_hist(P.m, 0.0), alpha(P.m, 0.0);
+  std::vector<double> ys_hist(P.m, 0.0);
   int head = 0, count = 0;  // ring: newest at (head-1) mod m
 
   for (float **p : {&csr->d_cache_x, &csr->d_cache_off, &csr->d_cache_gl})
@@ -1896,9 +1951,10 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   int evals = 0, iters = 0, fwd_sweeps = 0, tr_sweeps = 0;
   bool gl_at_x = true;  // d_cache_gl is the loss gradient at the current x
   // a full evaluation: objective, gradient, and (for the line search from the margins) the margins
-  auto full_eval = [&](bool new_point) -> int {
+  double dg_eval = 0;  // g . d at the point of the last full evaluation that asked for it
+  auto full_eval = [&](bool new_point, const float *dir = nullptr) -> int {
     ADMM_TRY(logistic_fg(csr, x, offset, z, ydual, rho, &f, g, &loss, from_margins ? csr->d_margin : nullptr,
-                         csr->d_cache_gl));
+                         csr->d_cache_gl, dir, &dg_eval));
     gl_at_x = true;
     if (from_margins) csr->margin_age = 0;
     if (new_point) ++evals;
@@ -2000,8 +2056,14 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     ++csr->margin_age;
     return ADMM_OK;
   };
-  ADMM_TRY(vec_dot(ctx, x, x, dim, &xx));
-  ADMM_TRY(vec_dot(ctx, g, g, dim, &gg));
+  if (!ctx->d_lb) ADMM_HIP_CHECK(hipMalloc(&ctx->d_lb, sizeof(double) * 64));
+  {
+    const DotReq rq[2] = {{x, x}, {g, g}};
+    double out[2];
+    ADMM_TRY(dots(ctx, rq, 2, dim, out));
+    xx = out[0];
+    gg = out[1];
+  }
   auto done = [&]() -> int {
     // remember where this solve ended
     if (gl_at_x) {
@@ -2062,7 +2124,9 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
         have_dg = true;
       } else {
         ADMM_TRY(vec_lincomb(ctx, x, xp, (float)step, d, dim));
-        ADMM_TRY(full_eval(true));
+        ADMM_TRY(full_eval(true, d));  // g . d comes back with the objective: one host round trip per trial point
+        dg = dg_eval;
+        have_dg = true;
       }
       ++ls;
       double width;
@@ -2103,14 +2167,19 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       break;
     }
     ++iters;
-    ADMM_TRY(vec_dot(ctx, x, x, dim, &xx));
-    ADMM_TRY(vec_dot(ctx, g, g, dim, &gg));
-    if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) <= P.epsilon) break;
     ADMM_TRY(vec_sub(ctx, s_new, x, xp, dim));
     ADMM_TRY(vec_sub(ctx, y_new, g, gp, dim));
     double ys = 0, yy = 0;
-    ADMM_TRY(vec_dot(ctx, y_new, s_new, dim, &ys));
-    ADMM_TRY(vec_dot(ctx, y_new, y_new, dim, &yy));
+    {
+      const DotReq rq[4] = {{x, x}, {g, g}, {y_new, s_new}, {y_new, y_new}};
+      double out[4];
+      ADMM_TRY(dots(ctx, rq, 4, dim, out));
+      xx = out[0];
+      gg = out[1];
+      ys = out[2];
+      yy = out[3];
+    }
+    if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) <= P.epsilon) break;
     if (ys > 1e-30) {
       // only a pair with positive curvature enters the ring (a rejected one must not overwrite the
       // oldest pair that is still in use)
@@ -2120,21 +2189,26 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       head = (head + 1) % P.m;
       if (count < P.m) ++count;
     }
+    // two-loop recursion; its coefficients stay on the device (no host round trip inside)
     ADMM_TRY(vec_lincomb(ctx, d, g, -2.0f, g, dim));  // d = -g
+    const int egrid = grid_for(dim, 256, ctx->cu_count * 8);
+    double *tmp = ctx->d_scalars + 3;  // where dots_async leaves its first product
     for (int i = 0; i < count; ++i) {  // newest -> oldest
       const int idx = (head - 1 - i + 2 * P.m) % P.m;
-      double sd = 0;
-      ADMM_TRY(vec_dot(ctx, S + (uint64_t)idx * dim, d, dim, &sd));
-      alpha[i] = sd / ys_hist[idx];
-      ADMM_TRY(vec_axpy(ctx, d, (float)(-alpha[i]), Y + (uint64_t)idx * dim, dim));
+      const DotReq rq = {S + (uint64_t)idx * dim, d};
+      ADMM_TRY(dots_async(ctx, &rq, 1, dim));
+      hipLaunchKernelGGL(k_axpy_coef, dim3(egrid), dim3(256), 0, ctx->stream, d, Y + (uint64_t)idx * dim, dim, tmp,
+                         ys_hist[idx], ctx->d_lb + i, 0);
+      ADMM_HIP_CHECK(hipGetLastError());
     }
     if (ys > 1e-30) ADMM_TRY(vec_scale(ctx, d, (float)(ys / yy), dim));
     for (int i = count - 1; i >= 0; --i) {  // oldest -> newest
       const int idx = (head - 1 - i + 2 * P.m) % P.m;
-      double yd = 0;
-      ADMM_TRY(vec_dot(ctx, Y + (uint64_t)idx * dim, d, dim, &yd));
-      const double beta = yd / ys_hist[idx];
-      ADMM_TRY(vec_axpy(ctx, d, (float)(alpha[i] - beta), S + (uint64_t)idx * dim, dim));
+      const DotReq rq = {Y + (uint64_t)idx * dim, d};
+      ADMM_TRY(dots_async(ctx, &rq, 1, dim));
+      hipLaunchKernelGGL(k_axpy_coef, dim3(egrid), dim3(256), 0, ctx->stream, d, S + (uint64_t)idx * dim, dim, tmp,
+                         ys_hist[idx], ctx->d_lb + i, 1);
+      ADMM_HIP_CHECK(hipGetLastError());
     }
     step = 1.0;
   }

@@ -156,7 +156,9 @@ class Worker:
     def BaseUpdate(self, train_parts, admm_params, global_weights):
         """src/workers.cc:51-87.  train_parts: the worker's data parts as capi.SampleSet."""
         if admm_params.local_solver == "lbfgs":
-            assert len(train_parts) == 1, "the L-BFGS local solver takes one resident part"
+            # the batch objective is a sum over all rows: a file's parts are loaded as ONE resident set
+            # for this solver (host/solvers.cc does the same), whatever num_part says
+            assert len(train_parts) == 1, "the L-BFGS local solver takes the shard as one resident set"
             return train_parts[0].lbfgs_solve(self.base_vec_, offset=self.bias_vec_, z=global_weights,
                                               ydual=self.langr_vec_, rho=admm_params.step_size,
                                               **admm_params.lbfgs)

@@ -56,9 +56,13 @@ void Worker::InitWorker(std::size_t fdim) {
 void Worker::BaseUpdate(SampleSet &, SampleSet &test_set, const AdmmConfig &admm_params) {
   if (parts_.empty()) {
     const std::string train_name = admm_params.train_path + "/" + psid_ + "_aggregated/part-00000";
-    for (int part = 0; part < num_part_; ++part) {
+    // The batch objective of the lbfgs solver is a sum over all rows, whatever the file's partition:
+    // its num_part pieces are loaded as one resident set (the reference splits a file into parts to
+    // bound the host memory of one load, src/workers.cc:73-77; HBM holds the whole shard).
+    const int nparts = admm_params.local_solver == "lbfgs" ? 1 : num_part_;
+    for (int part = 0; part < nparts; ++part) {
       parts_.emplace_back(new SampleSet);
-      ADMM_CHECK(parts_.back()->Initialize(train_name, part, num_part_, admm_params.dim));
+      ADMM_CHECK(parts_.back()->Initialize(train_name, part, nparts, admm_params.dim));
       if (admm_params.local_solver == "lbfgs")
         parts_.back()->PrepareTransposed(0, 16384, true);
       else if (admm_params.ftrl_batch > 1)

@@ -94,6 +94,26 @@ def test_admm_program_matches_reference_loop(tmp_path, oracle):
         assert float(l) == pytest.approx(r["lines"][0][0], rel=5e-5)
 
 
+def test_lbfgs_solver_takes_a_partitioned_file_as_one_set(tmp_path):
+    """`psid : 3` with the lbfgs local solver: the batch objective is a sum over all rows, so the
+    three parts of the file are one resident set and the run equals the one with `psid : 1`"""
+    dim = 300
+    write_libsvm(str(tmp_path / "train" / "A_aggregated" / "part-00000"), make_synth_csr(1200, dim, 12, seed=111))
+    write_libsvm(str(tmp_path / "test" / "A_aggregated" / "part-00000"), make_synth_csr(300, dim, 12, seed=112))
+    outs = []
+    for nparts in (1, 3):
+        os.makedirs(tmp_path / ("out%d" % nparts))
+        conf = tmp_path / ("admm%d.conf" % nparts)
+        conf.write_text("step_size = 0.05\nbias_var = 0.01\nglobal_var = 4\nftrl_alpha = 0.1\npasses = 3\n"
+                        "local_solver = lbfgs\ndim = %d\nA : %d\n" % (dim, nparts))
+        out = _run([os.path.join(BIN, "admm"), str(conf), str(tmp_path / "train"), str(tmp_path / "test"),
+                    str(tmp_path / ("out%d" % nparts))])
+        lines = re.findall(r"^A \| ([0-9.]+) \| ([0-9.]+) \| (\d+)$", out, flags=re.M)
+        assert len(lines) == 3 and lines[0] != lines[2]
+        outs.append((lines, open(tmp_path / ("out%d" % nparts) / "admm_weight_A").read()))
+    assert outs[0] == outs[1]
+
+
 def test_admm_program_on_wtest_fixture(tmp_path):
     """the program on the reference's own one-row fixture (test/wtest.libsvm), one rank"""
     for d in ("train", "test"):
