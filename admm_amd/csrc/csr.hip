@@ -906,6 +906,136 @@ __global__ void __launch_bounds__(256) k_maxrowlen(const uint64_t *__restrict__ 
   }
 }
 
+// ---- previous-occurrence table of the sequential FTRL pass -------------------------------------
+//
+// dep[k] = (rows back << 16) | position in that row, of the last earlier row that stores entry k's
+// column; 0 when there is none within 65534 rows (or its position does not fit 16 bits).  Built on
+// the device: a stable sort of (column, entry index) pairs puts every entry next to the previous
+// entry of its column; rows are handled in chunks with a halo of 65535 rows before each.
+
+__global__ void __launch_bounds__(256) k_iota_from(uint32_t *v, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) v[i] = (uint32_t)i;
+}
+
+__device__ inline uint64_t dep_row_of(const uint64_t *__restrict__ rowptr, uint64_t lo, uint64_t hi, uint64_t k) {
+  // last row r in [lo, hi) with rowptr[r] <= k
+  while (hi - lo > 1) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= k) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256) k_dep_from_sorted(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ idx,
+                                                         uint64_t n, uint64_t e0, uint64_t first_own,
+                                                         const uint64_t *__restrict__ rowptr, uint64_t row_lo, uint64_t row_hi,
+                                                         uint32_t *__restrict__ dep) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const uint64_t k = e0 + idx[i];
+    if (k < first_own) continue;  // a halo entry: its own chunk has written it
+    uint32_t d = 0;
+    if (i > 0 && keys[i - 1] == keys[i]) {
+      const uint64_t kp = e0 + idx[i - 1];
+      const uint64_t r = dep_row_of(rowptr, row_lo, row_hi, k), rp = dep_row_of(rowptr, row_lo, row_hi, kp);
+      const uint64_t back = r - rp, pos = kp - rowptr[rp];
+      if (back < 0xFFFFull && pos < 0x10000ull) d = ((uint32_t)back << 16) | (uint32_t)pos;
+    }
+    dep[k] = d;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_map_cols(const uint32_t *__restrict__ col, const uint32_t *__restrict__ perm,
+                                                  uint32_t *__restrict__ out, uint64_t nnz) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += stride) out[i] = perm[col[i]];
+}
+
+int build_dep(admm_csr *csr) {
+  if (csr->d_dep) return ADMM_OK;
+  admm_ctx *ctx = csr->ctx;
+  const uint64_t nrows = csr->nrows, nnz = csr->nnz;
+  {  // longest row
+    const int g = grid_for(std::max<uint64_t>(nrows, 1), 256, ctx->cu_count * 8);
+    hipLaunchKernelGGL(k_maxrowlen, dim3(g), dim3(256), 0, ctx->stream, csr->d_rowptr, nrows, ctx->d_partials);
+    ADMM_HIP_CHECK(hipGetLastError());
+    std::vector<double> hp(g);
+    ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), ctx->d_partials, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+    ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double m = 0;
+    for (double v : hp) m = std::max(m, v);
+    csr->max_row_len = (uint64_t)m;
+  }
+  if (csr->d_perm && nnz) {  // relabelled set: the pass addresses the state by original ids; translate once
+    ADMM_HIP_CHECK(hipMalloc(&csr->d_seqcol, sizeof(uint32_t) * (nnz + 8)));
+    hipLaunchKernelGGL(k_map_cols, dim3(grid_for(nnz, 256, ctx->cu_count * 16)), dim3(256), 0, ctx->stream, csr->d_col,
+                       csr->d_perm, csr->d_seqcol, nnz);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  ADMM_HIP_CHECK(hipMalloc(&csr->d_dep, sizeof(uint32_t) * (nnz + 8)));
+  if (nnz == 0) return ADMM_OK;
+  const uint64_t halo = 0xFFFF;
+  const uint64_t avg = std::max<uint64_t>(1, nnz / std::max<uint64_t>(nrows, 1));
+  uint64_t chunk_rows = std::max<uint64_t>(4 * halo, (192ull << 20) / avg);  // about 2e8 entries per sort
+  if (const char *env = getenv("ADMM_DEP_CHUNK_ROWS")) chunk_rows = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));  // test aid
+  int bits = 1;
+  while ((1ull << bits) < csr->dim) ++bits;
+  uint32_t *keys_out = nullptr, *idx_in = nullptr, *idx_out = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  uint64_t cap = 0;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)keys_out, (void *)idx_in, (void *)idx_out, tmp})
+      if (p) hipFree(p);
+    keys_out = idx_in = idx_out = nullptr;
+    tmp = nullptr;
+  };
+  auto fail = [&](hipError_t e, const char *what) {
+    set_error("sequential FTRL pass, previous-occurrence table: %s: %s", what, hipGetErrorString(e));
+    cleanup();
+    hipFree(csr->d_dep);
+    csr->d_dep = nullptr;
+    return e == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;
+  };
+  for (uint64_t c0 = 0; c0 < nrows; c0 += chunk_rows) {
+    const uint64_t c1 = std::min(nrows, c0 + chunk_rows), h0 = c0 > halo ? c0 - halo : 0;
+    uint64_t edge[3];
+    hipError_t e = hipMemcpyAsync(&edge[0], csr->d_rowptr + h0, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&edge[1], csr->d_rowptr + c0, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&edge[2], csr->d_rowptr + c1, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(e, "reading row pointers");
+    const uint64_t e0 = edge[0], n = edge[2] - edge[0];
+    if (n == 0) continue;
+    if (n >= 0xFFFFFFFFull) return fail(hipErrorInvalidValue, "more than 2^32 entries in one chunk of rows");
+    if (n > cap) {
+      cleanup();
+      cap = n;
+      if ((e = hipMalloc(&keys_out, sizeof(uint32_t) * cap)) != hipSuccess) return fail(e, "hipMalloc");
+      if ((e = hipMalloc(&idx_in, sizeof(uint32_t) * cap)) != hipSuccess) return fail(e, "hipMalloc");
+      if ((e = hipMalloc(&idx_out, sizeof(uint32_t) * cap)) != hipSuccess) return fail(e, "hipMalloc");
+      tmp_bytes = 0;
+      e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, csr->d_col, keys_out, idx_in, idx_out, (int64_t)cap, 0, bits,
+                                             ctx->stream);
+      if (e != hipSuccess) return fail(e, "sort size query");
+      if ((e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16))) != hipSuccess) return fail(e, "hipMalloc");
+    }
+    hipLaunchKernelGGL(k_iota_from, dim3(grid_for(n, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, idx_in, n);
+    size_t bytes = tmp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, csr->d_col + e0, keys_out, idx_in, idx_out, (int64_t)n, 0, bits, ctx->stream);
+    if (e != hipSuccess) return fail(e, "sort");
+    hipLaunchKernelGGL(k_dep_from_sorted, dim3(grid_for(n, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, keys_out,
+                       idx_out, n, e0, edge[1], csr->d_rowptr, h0, c1, csr->d_dep);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return fail(e, "synchronize");
+  cleanup();
+  return ADMM_OK;
+}
+
 int build_forward_panels(admm_csr *csr) {
   admm_ctx *ctx = csr->ctx;
   for (void **p : {(void **)&csr->d_fcol, (void **)&csr->d_frow, (void **)&csr->d_fval, (void **)&csr->d_fptr,

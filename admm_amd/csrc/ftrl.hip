@@ -394,47 +394,7 @@ __global__ void __launch_bounds__(64) k_ftrl_seq_multi(const MultiEntry *__restr
   }
 }
 
-// (rows_back << 16) | position for every stored entry, computed on the host from the device CSR
-static int ensure_dep(admm_csr *csr) {
-  if (csr->d_dep) return ADMM_OK;
-  admm_ctx *ctx = csr->ctx;
-  std::vector<uint64_t> rowptr(csr->nrows + 1);
-  std::vector<uint32_t> col(csr->nnz);
-  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  ADMM_HIP_CHECK(hipMemcpy(rowptr.data(), csr->d_rowptr, sizeof(uint64_t) * (csr->nrows + 1), hipMemcpyDeviceToHost));
-  if (csr->nnz) ADMM_HIP_CHECK(hipMemcpy(col.data(), csr->d_col, sizeof(uint32_t) * csr->nnz, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> dep(csr->nnz);
-  std::vector<int64_t> last_row(csr->dim, -1);
-  std::vector<uint32_t> last_pos(csr->dim, 0);
-  uint64_t max_len = 0;
-  for (uint64_t r = 0; r < csr->nrows; ++r) {
-    const uint64_t b = rowptr[r], e = rowptr[r + 1];
-    max_len = std::max(max_len, e - b);
-    for (uint64_t k = b; k < e; ++k) {
-      const uint32_t c = col[k];
-      uint32_t d = 0;
-      if (last_row[c] >= 0) {
-        const uint64_t back = r - (uint64_t)last_row[c];
-        if (back < 0xFFFF && last_pos[c] < 0x10000u) d = ((uint32_t)back << 16) | last_pos[c];
-      }
-      dep[k] = d;
-      last_row[c] = (int64_t)r;
-      last_pos[c] = (uint32_t)std::min<uint64_t>(k - b, 0xFFFFFFFFull);
-    }
-  }
-  csr->max_row_len = max_len;
-  if (csr->d_perm && csr->nnz) {
-    // relabelled set: the pass addresses the state by original ids; translate once
-    std::vector<uint32_t> perm(csr->dim);
-    ADMM_HIP_CHECK(hipMemcpy(perm.data(), csr->d_perm, sizeof(uint32_t) * csr->dim, hipMemcpyDeviceToHost));
-    for (uint64_t k = 0; k < csr->nnz; ++k) col[k] = perm[col[k]];
-    ADMM_HIP_CHECK(hipMalloc(&csr->d_seqcol, sizeof(uint32_t) * (csr->nnz + 8)));
-    ADMM_HIP_CHECK(hipMemcpy(csr->d_seqcol, col.data(), sizeof(uint32_t) * csr->nnz, hipMemcpyHostToDevice));
-  }
-  ADMM_HIP_CHECK(hipMalloc(&csr->d_dep, sizeof(uint32_t) * (csr->nnz + 8)));
-  if (csr->nnz) ADMM_HIP_CHECK(hipMemcpy(csr->d_dep, dep.data(), sizeof(uint32_t) * csr->nnz, hipMemcpyHostToDevice));
-  return ADMM_OK;
-}
+static int ensure_dep(admm_csr *csr) { return build_dep(csr); }
 
 int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,
                          float alpha, float beta, float l1, float l2) {

@@ -209,6 +209,7 @@ int finish_partials(admm_ctx *ctx, int nscalars, int nblocks);
 
 int ensure_rowbuf(admm_csr *csr);
 int build_forward_panels(admm_csr *csr);  // csr.hip
+int build_dep(admm_csr *csr);             // csr.hip: previous-occurrence table of the sequential FTRL pass
 int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool column_stream);  // csr.hip
 int ensure_taccum(admm_csr *csr);
 

@@ -182,6 +182,36 @@ def test_ftrl_sequential_admm_constants(ctx, oracle):
         close(g, r, atol=1e-6)
 
 
+def test_ftrl_previous_occurrence_table_in_chunks(ctx, oracle, monkeypatch):
+    """the table behind the pipelined row-by-row pass is built in chunks of rows with a halo: tiny
+    chunks give the same pass, bit for bit, as one chunk; and a column whose last use lies more than
+    65534 rows back is read from memory again (no entry in the table)"""
+    from oracle import oracle as orc
+    dim = 5000
+    raw = make_synth_csr(3000, dim, 25, seed=35)
+    outs = []
+    for chunk in (None, "97"):
+        if chunk:
+            monkeypatch.setenv("ADMM_DEP_CHUNK_ROWS", chunk)
+        got, ref = _ftrl_both(ctx, oracle, raw, dim, (0.05, 1.0, 0.1, 1.0))
+        if chunk:
+            monkeypatch.delenv("ADMM_DEP_CHUNK_ROWS")
+        for g, r in zip(got, ref):
+            close(g, r, atol=1e-6 * max(1.0, np.abs(r).max()))
+        outs.append(got)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    # 70000 rows of one entry each; column 7 is stored by the first and the last row only
+    n = 70000
+    col = (8 + np.arange(n) % 50).astype(np.uint32)
+    col[0] = col[-1] = 7
+    far = orc.Csr(np.arange(n + 1, dtype=np.uint64), col, np.ones(n, np.float32),
+                  (np.arange(n) % 3 == 0).astype(np.float32), 100)
+    got, ref = _ftrl_both(ctx, oracle, far, 100, (0.05, 1.0, 0.1, 1.0))
+    for g, r in zip(got, ref):
+        close(g, r, atol=1e-6 * max(1.0, np.abs(r).max()))
+
+
 def test_ftrl_rows_with_repeated_columns(ctx, oracle):
     from oracle import oracle as orc
     rowptr = np.array([0, 3, 5, 8], np.uint64)
