@@ -214,6 +214,7 @@ class Job:
             adist.init("gloo" if self.share_gpu else "cpu:gloo,cuda:nccl")
         self.ctx = capi.Context(self.local_rank)
         self.allreduce_path = "single rank"
+        self.comm_stuck = False
         if self.share_gpu:
             self.ctx.rank, self.ctx.world = self.rank, self.world
             self.ctx.exchange = self._host_exchange
@@ -222,12 +223,28 @@ class Job:
         elif self.world > 1:
             self.allreduce_path = "admm_allreduce_sum_f32 (RCCL through libadmm_hip.so)"
             if args.allreduce == "lib":
-                try:
-                    adist.lib_comm_init(self.ctx)
-                    self.ctx.comm_selftest()
-                except capi.AdmmError as e:
-                    sys.stderr.write("rank %d: library communicator failed (%s); using torch.distributed\n" % (self.rank, e))
+                # communicator + self test in a thread of their own: an error OR no answer within two
+                # minutes sends every rank to torch.distributed's all-reduce instead
+                import threading
+                state = {}
+
+                def bring_up():
+                    try:
+                        torch.cuda.set_device(self.local_rank)
+                        adist.lib_comm_init(self.ctx)
+                        self.ctx.comm_selftest()
+                        state["ok"] = True
+                    except Exception as e:   # noqa: BLE001 - reported below, the run goes on without the library path
+                        state["error"] = e
+
+                th = threading.Thread(target=bring_up, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("ADMM_BENCH_COMM_TIMEOUT", "120")))
+                if not state.get("ok"):
+                    why = state.get("error", "no answer in time")
+                    sys.stderr.write("rank %d: library communicator failed (%s); using torch.distributed\n" % (self.rank, why))
                     args.allreduce = "torch"
+                    self.comm_stuck = th.is_alive()
             ok = self.host_sum([1.0 if args.allreduce == "lib" else 0.0])[0]
             if ok != self.world:        # every rank takes the same path
                 args.allreduce = "torch"
@@ -266,6 +283,10 @@ class Job:
         self.torch.cuda.synchronize()
 
     def close(self):
+        if self.comm_stuck:      # a thread still sits in the communicator's bring-up: leave without joining it
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         self.ctx.close()
         self.adist.finalize()
 

@@ -43,6 +43,19 @@ def test_zero_weight_prediction(oracle, known):
     assert "%.7f" % ll == known["zero_weight_logloss"]
 
 
+def test_prediction_ignores_assigned_weights(oracle):
+    """test/ftrl_test.cc:28-49: FtrlSolver(0.1, 0.2, 1, 1, 1, 5) predicts 0.5 on the row {1:1.0, 3:2.0, 4:1.4}
+    at zero state, and still 0.5 after Assign(all 2.0): Predict takes the lazy weights from z and n
+    (src/ftrl.cc:54-75), not from weight_"""
+    col = np.array([1, 3, 4], np.uint32)
+    val = np.array([1.0, 2.0, 1.4], np.float32)
+    dim = 5
+    z, n, off, reg = (np.zeros(dim, np.float32) for _ in range(4))
+    for w in (np.zeros(dim, np.float32), np.full(dim, 2.0, np.float32)):
+        p = oracle.lib().orc_ftrl_predict(col, val.ctypes.data, 3, w, z, n, off, reg, 0.1, 0.2, 1.0, 1.0)
+        assert p == 0.5
+
+
 def test_ftrl_passes_known_answers(oracle, known):
     _, tr = _wtest(oracle)
     prm = known["ftrl_params"]
