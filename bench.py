@@ -366,8 +366,8 @@ def run_admm(args):
         scaling = "strong"
     t_gen = time.perf_counter()
     train = ctx.csr_synth(r1 - r0, args.dim, args.mean_nnz, seed=args.seed, row_offset=r0, **synth_kw(args))
+    train.relabel_by_frequency()          # first: the copies are then built once, in the final numbering
     train.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
-    train.relabel_by_frequency()
     n_test = max(1, int((r1 - r0) * args.test_frac))
     test = ctx.csr_synth(n_test, args.dim, args.mean_nnz, seed=args.seed + 1, row_offset=r0, **synth_kw(args))
     test.relabel_by_frequency()
@@ -530,8 +530,8 @@ def run_ftrl(args):
     prm = (0.01, 1.0, 0.4, 2.5)                                # script/start.sh:15-31
     t_gen = time.perf_counter()
     train = ctx.csr_synth(r1 - r0, dim, args.mean_nnz, seed=args.seed, row_offset=r0, **synth_kw(args))
-    train.build_transposed(panel_rows=batch, col_block=args.col_block)
     train.relabel_by_frequency()
+    train.build_transposed(panel_rows=batch, col_block=args.col_block)
     test = ctx.csr_synth(max(1, int((r1 - r0) * args.test_frac)), dim, args.mean_nnz, seed=args.seed + 1,
                          row_offset=r0, **synth_kw(args))
     ctx.sync()
