@@ -906,6 +906,114 @@ __global__ void __launch_bounds__(256) k_maxrowlen(const uint64_t *__restrict__ 
   }
 }
 
+// ---- order of the entries inside the cells of the column-block copy ----------------------------
+//
+// The builder leaves a cell's entries grouped by runs of 512 rows, in no particular order inside a
+// run.  Any order gives the same sums; the one that makes the sweep's gathers of the per-row vector
+// cheap is: rows ascending, and inside every aligned group of 256 entries (what one wavefront takes
+// with its 16-byte loads, four entries per lane) entry 64 c + l at position 4 l + c -- so that
+// component c of the 64 lanes is 64 consecutive entries, adjacent lanes gather adjacent rows, and
+// the address unit, which takes a gather four lanes at a time, finds them in the same line.
+
+__global__ void __launch_bounds__(256) k_cell_offsets(const uint64_t *__restrict__ tptr, uint64_t first_cell, uint32_t nblocks,
+                                                      uint32_t *__restrict__ off) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i <= nblocks) off[i] = (uint32_t)(tptr[first_cell + i] - tptr[first_cell]);
+}
+
+__global__ void __launch_bounds__(256) k_cell_reorder(const uint32_t *__restrict__ sorted_row, const uint32_t *__restrict__ src,
+                                                      const uint16_t *__restrict__ col_old, const float *__restrict__ val_old,
+                                                      const uint32_t *__restrict__ off, uint32_t nblocks, uint64_t e0,
+                                                      uint32_t n, uint32_t *__restrict__ trow, uint16_t *__restrict__ tcol,
+                                                      float *__restrict__ tval) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    // the cell that holds panel-relative position i
+    uint32_t lo = 0, hi = nblocks;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (off[mid] <= i) lo = mid;
+      else hi = mid;
+    }
+    const uint64_t beg = e0 + off[lo], end = e0 + off[lo + 1];
+    const uint64_t body0 = (beg + 3) & ~3ull, body1 = end & ~3ull;
+    uint64_t k = e0 + i;
+    if (k >= body0 && body0 < body1) {
+      const uint64_t rel = k - body0, chunk = rel >> 8;
+      if (body0 + ((chunk + 1) << 8) <= body1) {
+        const uint32_t u = (uint32_t)(rel & 255u);
+        k = body0 + (chunk << 8) + 4 * (u & 63u) + (u >> 6);
+      }
+    }
+    const uint32_t from = src[i];
+    trow[k] = sorted_row[i];
+    tcol[k] = col_old[from];
+    if (tval) tval[k] = val_old[from];
+  }
+}
+
+static int sort_cells(admm_csr *csr) {
+  admm_ctx *ctx = csr->ctx;
+  {
+    const char *env = getenv("ADMM_CELL_SORT");  // 0: leave the cells as the builder wrote them
+    if (env && env[0] == '0') return ADMM_OK;
+  }
+  if (csr->tnnz == 0) return ADMM_OK;
+  uint64_t cap = 0;
+  for (uint64_t p = 0; p < csr->npanels; ++p)
+    cap = std::max(cap, csr->h_tptr[(p + 1) * csr->nblocks] - csr->h_tptr[p * csr->nblocks]);
+  if (cap == 0 || cap >= 0x7FFFFFFFull) return ADMM_OK;  // a panel beyond the sort's index range keeps its order
+  int bits = 1;
+  while ((1ull << bits) < csr->nrows && bits < 32) ++bits;
+  uint32_t *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *off = nullptr;
+  uint16_t *col_old = nullptr;
+  float *val_old = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  auto cleanup = [&]() {
+    for (void *q : {(void *)keys, (void *)idx_in, (void *)idx_out, (void *)off, (void *)col_old, (void *)val_old, tmp})
+      if (q) hipFree(q);
+  };
+#define SC_CHECK(expr)                                                            \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      set_error("admm_csr_build_transposed (cell order): %s: %s", #expr, hipGetErrorString(e_)); \
+      cleanup();                                                                  \
+      return e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;           \
+    }                                                                             \
+  } while (0)
+  SC_CHECK(hipMalloc(&keys, sizeof(uint32_t) * cap));
+  SC_CHECK(hipMalloc(&idx_in, sizeof(uint32_t) * cap));
+  SC_CHECK(hipMalloc(&idx_out, sizeof(uint32_t) * cap));
+  SC_CHECK(hipMalloc(&off, sizeof(uint32_t) * (csr->nblocks + 1)));
+  SC_CHECK(hipMalloc(&col_old, sizeof(uint16_t) * cap));
+  if (csr->d_tval) SC_CHECK(hipMalloc(&val_old, sizeof(float) * cap));
+  SC_CHECK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp_bytes, csr->d_trow, keys, idx_in, idx_out, (int)cap,
+                                                       (int)csr->nblocks, off, off + 1, 0, bits, ctx->stream));
+  SC_CHECK(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+  hipLaunchKernelGGL(k_iota, dim3(grid_for(cap, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, idx_in, cap);
+  for (uint64_t p = 0; p < csr->npanels; ++p) {
+    const uint64_t first = p * csr->nblocks, e0 = csr->h_tptr[first];
+    const uint32_t n = (uint32_t)(csr->h_tptr[first + csr->nblocks] - e0);
+    if (n == 0) continue;
+    hipLaunchKernelGGL(k_cell_offsets, dim3((csr->nblocks + 256) / 256), dim3(256), 0, ctx->stream, csr->d_tptr, first,
+                       csr->nblocks, off);
+    size_t bytes = tmp_bytes;
+    SC_CHECK(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp, bytes, csr->d_trow + e0, keys, idx_in, idx_out, (int)n,
+                                                         (int)csr->nblocks, off, off + 1, 0, bits, ctx->stream));
+    SC_CHECK(hipMemcpyAsync(col_old, csr->d_tcol + e0, sizeof(uint16_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (val_old) SC_CHECK(hipMemcpyAsync(val_old, csr->d_tval + e0, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_cell_reorder, dim3(grid_for(n, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, keys, idx_out,
+                       col_old, val_old, off, csr->nblocks, e0, n, csr->d_trow, csr->d_tcol, csr->d_tval);
+    SC_CHECK(hipGetLastError());
+  }
+  SC_CHECK(hipStreamSynchronize(ctx->stream));
+#undef SC_CHECK
+  cleanup();
+  return ADMM_OK;
+}
+
 // ---- previous-occurrence table of the sequential FTRL pass -------------------------------------
 //
 // dep[k] = (rows back << 16) | position in that row, of the last earlier row that stores entry k's
@@ -1598,6 +1706,7 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   }
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   hipFree(d_cnt);
+  ADMM_TRY(sort_cells(csr));
   // fixed-point scale of the accumulators: |r * val| <= vmax for |r| <= 1, at most panel_rows
   // addends per column and cell, everything below 2^61
   csr->vmax = 1.0f;
