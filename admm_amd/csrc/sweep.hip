@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
 //   to the margin of the entry's row -- goes to LDS, where an integer atomic costs one lane-clock.
 // Integer adds commute: the margins do not depend on the order of the entries, and a sweep is
 // bit-reproducible.  The fixed-point shift is chosen per sweep on the device from max |w|
-// (k_wsum_absmax, k_fp_shift), the largest |value| and the longest row, so that no row sum can
+// (k_wsum_absmax leaves it per workgroup), the largest |value| and the longest row, so that no row sum can
 // reach 2^50.
 //
 // Entries in the most frequent kMaskCols columns of a relabelled set are not in the copy: they are
@@ -630,14 +630,18 @@ struct RpArgs {
   const uint32_t *perm;    // stored id -> caller's id (relabelled sets), for the column sums' destination
   uint32_t nhot;           // leading entries of w cached in LDS
   const float *w;          // gathered vector in the set's stored column order
-  const int *shift;        // fixed-point shift of this sweep
+  const float *blockmax;   // max |w| per workgroup of the kernel that filled w; the sweep's fixed-point shift follows from it
+  int nblockmax, lenbits;  // (lenbits: ceil(log2(longest row + 1)))
+  float vmax;              // max |value| of the set
   uint64_t nrows;
   uint32_t panel_rows;
   int add_bias;            // no mask tier, bias column left out of the copy: every margin starts at w[0]
   float *out, *out2;
   double *partials;
   unsigned long long *g1;  // X^T r of the mask columns goes here (fixed point, gscale), nullptr: not wanted
+  unsigned long long *g2;  // FTRL form: the sums of the squared gradients of those columns
   float gscale;
+  uint64_t panel0, pcount; // panels [panel0, panel0 + pcount) are swept by this launch
 };
 
 // An integer-valued double of magnitude below 2^51 as a 64-bit integer: adding 1.5 * 2^52 leaves the
@@ -655,13 +659,33 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   __shared__ float raw[kMaskCols];                                   // weights of the mask columns
   __shared__ float tab[8 * 256];                                     // byte of the first mask word -> sum of its weights
   __shared__ unsigned long long wacc[kMaskCols];                     // X^T r of the mask columns, this workgroup
+  __shared__ unsigned long long wacc2[MODE == FWD_FTRL ? kMaskCols : 1];  // FTRL form: squared-gradient sums of those columns
   __shared__ double shred[kRpThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool dense = a.hmask != nullptr;
-  const bool colsums = dense && MODE == FWD_LBFGS && a.g1 != nullptr;
+  const bool colsums = dense && (MODE == FWD_LBFGS || MODE == FWD_FTRL) && a.g1 != nullptr;
   const uint32_t R = a.panel_rows;
-  const uint64_t npanels = (a.nrows + R - 1) / R;
-  const int shift = *a.shift;
+  // the fixed-point shift of this sweep: the largest s with (longest row) * max |w v| * 2^s < 2^50, at
+  // most 40 -- a margin, and every partial sum of one, then is an integer below 2^51 in magnitude,
+  // which a double holds exactly.  Every workgroup derives it from the same maxima.
+  {
+    float mx = 0.0f;
+    for (int i = tid; i < a.nblockmax; i += kRpThreads) mx = fmaxf(mx, a.blockmax[i]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    if (lane == 0) shred[wave] = (double)mx;
+    __syncthreads();
+  }
+  int shift;
+  {
+    float top = 0.0f;
+    for (int w8 = 0; w8 < kRpThreads / 64; ++w8) top = fmaxf(top, (float)shred[w8]);
+    top *= a.vmax;
+    int e = 0;
+    if (top > 0.0f && top < 3.0e38f) frexpf(top, &e);  // top < 2^e
+    else if (!(top < 3.0e38f)) e = 128;
+    shift = 50 - a.lenbits - e;
+    shift = shift > 40 ? 40 : (shift < -60 ? -60 : shift);
+  }
   const float scale = ldexpf(1.0f, shift);
   const double inv_scale = ldexp(1.0, -shift);
   for (uint32_t j = tid; j < a.nhot; j += kRpThreads) {
@@ -671,6 +695,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   if (tid == 0) hot[a.nhot] = 0.0f;
   if (tid < (int)kMaskCols) {
     wacc[tid] = 0ull;
+    if (MODE == FWD_FTRL) wacc2[tid] = 0ull;
     raw[tid] = dense ? a.w[tid] : 0.0f;  // a set with masks has at least kMaskCols columns
   }
   __syncthreads();
@@ -688,7 +713,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   double acc0 = 0, acc1 = 0;
   i32x4 cacc[4] = {};  // column sums of the first mask word, by digit (see the epilogue)
   __syncthreads();
-  for (uint64_t p = blockIdx.x; p < npanels; p += gridDim.x) {
+  for (uint64_t p = a.panel0 + blockIdx.x; p < a.panel0 + a.pcount; p += gridDim.x) {
     const uint64_t r0 = p * R;
     const uint32_t nr = (uint32_t)(a.nrows - r0 < R ? a.nrows - r0 : R);
     // ---- margins start at the mask tier's part (or at the bias weight)
@@ -793,12 +818,22 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
     for (uint32_t rb = wave * 64; rb < nr; rb += kRpThreads) {
       const uint32_t r = rb + lane;
       const bool on = r < nr;
-      unsigned long long rv = 0;
+      unsigned long long rv = 0, rv2 = 0;
       if (on) {
         const float m = (float)((double)(long long)rp_acc[r] * inv_scale);
         const float lab = a.label[r0 + r];
         if (MODE == FWD_MARGIN) {
           a.out[r0 + r] = m;
+        } else if (MODE == FWD_FTRL) {
+          // src/ftrl.cc:72,76-78
+          const float pr = (float)(1.0 / (1 + exp(-(double)clamp35(m))));
+          const int y = lab > 0 ? 1 : 0;
+          const float g = pr - y;
+          a.out[r0 + r] = g;
+          rv = (unsigned long long)(long long)(g * a.gscale);
+          rv2 = (unsigned long long)(long long)(g * g * a.gscale) | 1ull;  // non-zero marks "touched"
+          acc0 += (double)g;
+          acc1 += (double)(g * g);
         } else if (MODE == FWD_EVAL) {
           // src/metrics.cc:104-105: double predict, -log p / -log(1-p)
           const double pd = 1.0f / (1 + exp(-(double)clamp35(m)));
@@ -825,12 +860,21 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         // broadcast and ballot for all four words were slower: 1.90 against 1.64 ms per 10M rows).
         {
           const unsigned long long u = rv + (1ull << 41);  // |rv| <= 2^37
-          unsigned char *pl = reinterpret_cast<unsigned char *>(rp_acc + rb);
+          // (FTRL form: six more digits for the squared gradient, in the same B operand; its thirteen
+          // planes have a 1 KB slot per wave behind the weight table)
+          unsigned char *pl = MODE == FWD_FTRL
+                                  ? reinterpret_cast<unsigned char *>(hot + ((a.nhot + 1 + 3) & ~3u)) + wave * 1024
+                                  : reinterpret_cast<unsigned char *>(rp_acc + rb);
 #pragma unroll
           for (int n = 0; n < 6; ++n) pl[n * 64 + lane] = (unsigned char)((u >> (7 * n)) & 127u);
           pl[6 * 64 + lane] = 1;
+          if (MODE == FWD_FTRL) {
+#pragma unroll
+            for (int n = 0; n < 6; ++n) pl[(7 + n) * 64 + lane] = (unsigned char)((rv2 >> (7 * n)) & 127u);
+          }
           i32x4 bfrag = {0, 0, 0, 0};
-          if ((lane & 15) < 7) bfrag = *reinterpret_cast<const i32x4 *>(pl + (lane & 15) * 64 + 16 * (lane >> 4));
+          if ((lane & 15) < (MODE == FWD_FTRL ? 13 : 7))
+            bfrag = *reinterpret_cast<const i32x4 *>(pl + (lane & 15) * 64 + 16 * (lane >> 4));
           const uint16_t *tt = reinterpret_cast<const uint16_t *>(a.hmaskT + (r0 + rb));
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
@@ -851,6 +895,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
           for (int w = 0; w < kWarmWords; ++w) {
             if (mw[w]) {
               atomicAdd(&wacc[64 * (w + 1) + __builtin_ctzll(mw[w])], rv);
+              if (MODE == FWD_FTRL) atomicAdd(&wacc2[64 * (w + 1) + __builtin_ctzll(mw[w])], rv2);
               mw[w] &= mw[w] - 1;
             }
           }
@@ -873,10 +918,13 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
           if (v) atomicAdd(&wacc[col], (unsigned long long)(v << (7 * digit)));
         } else if (digit == 6) {
           if (v) atomicAdd(&wacc[col], (unsigned long long)(-(v << 41)));
+        } else if (MODE == FWD_FTRL && digit < 13) {
+          if (v) atomicAdd(&wacc2[col], (unsigned long long)(v << (7 * (digit - 7))));
         }
       }
     __syncthreads();
     if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.g1 + a.perm[tid], wacc[tid]);
+    if (MODE == FWD_FTRL && tid < (int)kMaskCols && wacc2[tid]) atomicAdd(a.g2 + a.perm[tid], wacc2[tid]);
   }
   for (int off = 32; off > 0; off >>= 1) {
     acc0 += __shfl_down(acc0, off, 64);
@@ -927,30 +975,6 @@ __global__ void __launch_bounds__(256) k_wsum_absmax(const float *__restrict__ w
   if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
-// shift = the largest s with (longest row) * max |w v| * 2^s < 2^50, at most 40: a margin, and every
-// partial sum of one, then is an integer below 2^51 in magnitude, which a double holds exactly
-__global__ void __launch_bounds__(256) k_fp_shift(const float *__restrict__ blockmax, int nblocks, float vmax, int lenbits,
-                                                  int *__restrict__ shift_out) {
-  __shared__ float sh[256];
-  float m = 0.0f;
-  for (int i = threadIdx.x; i < nblocks; i += 256) m = fmaxf(m, blockmax[i]);
-  sh[threadIdx.x] = m;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + off]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const float top = sh[0] * vmax;
-    int e = 0;
-    if (top > 0.0f && top < 3.0e38f) frexpf(top, &e);  // top < 2^e
-    else if (!(top < 3.0e38f)) e = 128;
-    int s = 50 - lenbits - e;
-    s = s > 40 ? 40 : (s < -60 ? -60 : s);
-    *shift_out = s;
-  }
-}
-
 // wsum[j] = sum over the weight vectors of w_g[perm[j]]  (perm == nullptr: identity)
 __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, const float *__restrict__ w1,
                                               const float *__restrict__ w2, const float *__restrict__ w3,
@@ -968,18 +992,21 @@ __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, cons
 }
 
 // whole-set sweep over the row-panel copy
-static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const *w, int nw, float *out_rows,
-                                 int *nblocks_out, float *margins_out) {
+// grid of the kernels that fill csr->d_wsum and leave max |wsum| per workgroup behind
+static inline int wsum_grid(admm_ctx *ctx, uint64_t dim) { return grid_for(dim, 256, std::min(ctx->cu_count * 8, kMaxPartialBlocks)); }
+static inline float *wsum_blockmax(admm_ctx *ctx) { return reinterpret_cast<float *>(ctx->d_partials + 6 * (size_t)kMaxPartialBlocks); }
+
+// sweep over the row-panel copy: the whole set, or (r0, r1 on panel boundaries) a range of panels;
+// nw == 0: the caller has filled csr->d_wsum and the per-workgroup maxima itself
+static int launch_forward_panels(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
+                                 float *out_rows, int *nblocks_out, float *margins_out) {
   admm_ctx *ctx = csr->ctx;
-  const int wgrid = grid_for(csr->dim, 256, std::min(ctx->cu_count * 8, kMaxPartialBlocks));
-  float *blockmax = reinterpret_cast<float *>(ctx->d_partials + 6 * (size_t)kMaxPartialBlocks);
-  {
+  const int wgrid = wsum_grid(ctx, csr->dim);
+  float *blockmax = wsum_blockmax(ctx);
+  if (nw > 0) {
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_wsum_absmax, dim3(wgrid), dim3(256), 0, ctx->stream, w[0], nw > 1 ? w[1] : nullptr,
                        nw > 2 ? w[2] : nullptr, nw > 3 ? w[3] : nullptr, csr->d_perm, csr->d_wsum, csr->dim, blockmax);
-    ADMM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_fp_shift, dim3(1), dim3(256), 0, ctx->stream, blockmax, wgrid, csr->vmax, csr->fp_lenbits,
-                       csr->d_fp_shift);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   RpArgs a{};
@@ -1001,18 +1028,28 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
   }
   a.w = csr->d_wsum;
   a.nhot = csr->fp_hot;
-  a.shift = csr->d_fp_shift;
+  a.blockmax = blockmax;
+  a.nblockmax = wgrid;
+  a.lenbits = csr->fp_lenbits;
+  a.vmax = csr->vmax;
   a.nrows = csr->nrows;
   a.panel_rows = csr->fp_rows;
   a.out = out_rows;
   a.out2 = margins_out;
   a.partials = ctx->d_partials;
-  if (mode == FWD_LBFGS && csr->hot_dense) {
+  if (mode == FWD_LBFGS || mode == FWD_FTRL) {
     ADMM_REQUIRE(csr->has_t, "forward sweep: the training forms need admm_csr_build_transposed");
-    a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
     a.gscale = std::ldexp(1.0f, csr->fx_shift);
+    if (csr->hot_dense) {
+      a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
+      a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
+    }
   }
-  const size_t lds = sizeof(unsigned long long) * csr->fp_rows + sizeof(float) * (a.nhot + 1);
+  a.panel0 = r0 / csr->fp_rows;
+  a.pcount = (r1 - r0 + csr->fp_rows - 1) / csr->fp_rows;
+  // margins, the weight table (+ its filler slot, rounded to 16 bytes), and for the FTRL form 1 KB per wave
+  const size_t lds = sizeof(unsigned long long) * csr->fp_rows + sizeof(float) * ((a.nhot + 1 + 3) & ~3u) +
+                     (mode == FWD_FTRL ? (size_t)(kRpThreads / 64) * 1024 : 0);
   static bool raised[64] = {};
   if (!raised[ctx->device & 63]) {
     for (const void *fn : {reinterpret_cast<const void *>(&k_forward_rp<FWD_EVAL, true>),
@@ -1020,12 +1057,13 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
                            reinterpret_cast<const void *>(&k_forward_rp<FWD_LBFGS, true>),
                            reinterpret_cast<const void *>(&k_forward_rp<FWD_LBFGS, false>),
                            reinterpret_cast<const void *>(&k_forward_rp<FWD_MARGIN, true>),
-                           reinterpret_cast<const void *>(&k_forward_rp<FWD_MARGIN, false>)})
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_MARGIN, false>),
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_FTRL, true>),
+                           reinterpret_cast<const void *>(&k_forward_rp<FWD_FTRL, false>)})
       ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     raised[ctx->device & 63] = true;
   }
-  const uint64_t npanels = (csr->nrows + csr->fp_rows - 1) / csr->fp_rows;
-  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 2));  // two resident per CU
+  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(a.pcount, (uint64_t)ctx->cu_count * 2));  // two resident per CU
   *nblocks_out = grid;
   const bool hasval = a.hval != nullptr;
   KernelTimer t(ctx, mode == FWD_EVAL ? ADMM_K_FORWARD_EVAL : ADMM_K_FORWARD);
@@ -1036,6 +1074,8 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, const float *const
     RP_LAUNCH(FWD_EVAL)
   } else if (mode == FWD_LBFGS) {
     RP_LAUNCH(FWD_LBFGS)
+  } else if (mode == FWD_FTRL) {
+    RP_LAUNCH(FWD_FTRL)
   } else {
     RP_LAUNCH(FWD_MARGIN)
   }
@@ -1051,7 +1091,11 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   ADMM_REQUIRE(r0 <= r1 && r1 <= csr->nrows, "forward sweep: bad row range");
   if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
   if (csr->has_fp && nw > 0 && mode != FWD_FTRL && r0 == 0 && r1 == csr->nrows)
-    return launch_forward_panels(csr, mode, w, nw, out_rows, nblocks_out, margins_out);
+    return launch_forward_panels(csr, mode, r0, r1, w, nw, out_rows, nblocks_out, margins_out);
+  // a mini-batch of the FTRL pass: a range of whole panels, weights already in csr->d_wsum
+  if (csr->has_fp && nw == 0 && mode == FWD_FTRL && r0 < r1 && r0 % csr->fp_rows == 0 &&
+      (r1 % csr->fp_rows == 0 || r1 == csr->nrows))
+    return launch_forward_panels(csr, mode, r0, r1, w, nw, out_rows, nblocks_out, margins_out);
   if (nw > 0) {  // nw == 0: the caller has filled csr->d_wsum itself
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_wsum, dim3(grid_for(csr->dim, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, w[0],
@@ -1766,10 +1810,21 @@ __device__ inline float ftrl_weight(float z, float n, float c, float alpha, floa
 __global__ void __launch_bounds__(256) k_ftrl_wsum(const float *__restrict__ z, const float *__restrict__ n,
                                                    const float *__restrict__ c, const float *__restrict__ offset,
                                                    const uint32_t *__restrict__ inv, float alpha, float beta, float l1,
-                                                   float l2, float *__restrict__ wsum, uint64_t dim) {
+                                                   float l2, float *__restrict__ wsum, uint64_t count,
+                                                   const uint32_t *__restrict__ list, float *__restrict__ blockmax) {
+  __shared__ float sh[4];
   const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride)
-    wsum[inv ? inv[i] : i] = ftrl_weight(z[i], n[i], c[i], alpha, beta, l1, l2) + offset[i];
+  float m = 0.0f;
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < count; t += stride) {
+    const uint64_t i = list ? list[t] : t;  // list: the columns the batch stores (no other weight is read)
+    const float v = ftrl_weight(z[i], n[i], c[i], alpha, beta, l1, l2) + offset[i];
+    wsum[inv ? inv[i] : i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));  // for the sweep's fixed-point shift
 }
 
 // per coordinate touched in the batch (its squared-gradient sum is non-zero): w <- the lazy weight at
@@ -1780,9 +1835,10 @@ __global__ void __launch_bounds__(256) k_ftrl_apply(long long *__restrict__ g1, 
                                                     float *__restrict__ w, float *__restrict__ z,
                                                     float *__restrict__ n, float alpha, float beta, float l1, float l2,
                                                     const double *__restrict__ partials, int bias_blocks,
-                                                    uint64_t dim) {
+                                                    uint64_t count, const uint32_t *__restrict__ list) {
   const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < count; t += stride) {
+    const uint64_t i = list ? list[t] : t;
     const long long q2 = g2[i];
     bool touched = q2 != 0;
     double G1 = 0, G2 = 0;
@@ -1841,14 +1897,20 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
                (unsigned long long)batch, (unsigned long long)csr->panel_rows);
   ADMM_TRY(ensure_rowbuf(csr));
   if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
-  const int egrid = grid_for(csr->dim, 256, ctx->cu_count * 8);
   const bool bias_partials = csr->has_bias && !csr->hot_dense;
+  // columns no batch stores are never read: they only have to hold finite numbers
+  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_wsum, 0, sizeof(float) * csr->dim, ctx->stream));
+  const bool lists = csr->d_touch != nullptr && csr->h_touch_ptr.size() == csr->npanels + 1;
   for (uint64_t p = 0; p < csr->npanels; ++p) {
     const uint64_t r0 = p * csr->panel_rows, r1 = std::min(csr->nrows, r0 + csr->panel_rows);
+    // the per-coordinate passes visit the columns this batch stores (a list kept with the copy), or all
+    const uint64_t count = lists ? csr->h_touch_ptr[p + 1] - csr->h_touch_ptr[p] : csr->dim;
+    const uint32_t *list = lists ? csr->d_touch + csr->h_touch_ptr[p] : nullptr;
     {
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
-      hipLaunchKernelGGL(k_ftrl_wsum, dim3(egrid), dim3(256), 0, ctx->stream, z, n, reg_offset, offset, csr->d_inv,
-                         alpha, beta, l1, l2, csr->d_wsum, csr->dim);
+      // every workgroup of the full-size grid leaves a maximum: launch that grid (idle ones write 0)
+      hipLaunchKernelGGL(k_ftrl_wsum, dim3(wsum_grid(ctx, csr->dim)), dim3(256), 0, ctx->stream, z, n, reg_offset, offset,
+                         csr->d_inv, alpha, beta, l1, l2, csr->d_wsum, count, list, wsum_blockmax(ctx));
       ADMM_HIP_CHECK(hipGetLastError());
     }
     int nblk = 0;
@@ -1856,9 +1918,9 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
     ADMM_TRY(launch_transposed(csr, true, p, p + 1));
     {
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
-      hipLaunchKernelGGL(k_ftrl_apply, dim3(egrid), dim3(256), 0, ctx->stream, csr->d_g1, csr->d_g2,
-                         std::ldexp(1.0, -csr->fx_shift), reg_offset, w, z, n, alpha, beta, l1, l2, ctx->d_partials,
-                         bias_partials ? nblk : 0, csr->dim);
+      hipLaunchKernelGGL(k_ftrl_apply, dim3(grid_for(std::max<uint64_t>(count, 1), 256, ctx->cu_count * 8)), dim3(256), 0,
+                         ctx->stream, csr->d_g1, csr->d_g2, std::ldexp(1.0, -csr->fx_shift), reg_offset, w, z, n, alpha, beta,
+                         l1, l2, ctx->d_partials, bias_partials ? nblk : 0, count, list);
       ADMM_HIP_CHECK(hipGetLastError());
     }
   }

@@ -310,6 +310,34 @@ def test_ftrl_minibatch(ctx, oracle, batch):
         close(g, r, rtol=5e-5, atol=2e-6)    # float atomics order inside a batch
 
 
+@pytest.mark.parametrize("binary", [True, False])
+@pytest.mark.parametrize("relabel", [False, True])
+def test_ftrl_minibatch_on_panel_boundaries(ctx, oracle, relabel, binary):
+    """batches of 512 and 1024 rows: a multiple of the 256-row panels a mini-batch copy is cut into, so
+    the forward sweep of a batch runs over the row-panel copy (hot stream, lists, mask columns with
+    both sums); 40000 columns, so that entries fall outside the hot stream too"""
+    dim = 40000
+    raw = make_synth_csr(2900, dim, 40, seed=37, binary=binary)
+    tr = oracle.translate(raw)
+    rng = np.random.default_rng(17)
+    reg = rng.normal(0, 0.02, dim).astype(np.float32)
+    off = rng.normal(0, 0.02, dim).astype(np.float32)
+    for batch in (512, 1024):
+        hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+        dev = upload(ctx, raw, dim)
+        if relabel:
+            dev.relabel_by_frequency()
+        dev.build_transposed(panel_rows=batch, col_block=2048)
+        w, z, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+        doff, dreg = ctx.vec(dim, off), ctx.vec(dim, reg)
+        for _ in range(2):
+            oracle.ftrl_run(tr, hw, hz, hn, off, reg, 0.05, 1.0, 0.2, 1.5, batch=batch)
+            dev.ftrl_pass(w, z, n, doff, dreg, 0.05, 1.0, 0.2, 1.5, batch=batch)
+        for got, ref in ((w, hw), (z, hz), (n, hn)):
+            close(got.download(), ref, rtol=5e-5, atol=2e-6 * max(1.0, np.abs(ref).max()))
+        dev.destroy()
+
+
 # ------------------------------------------------------------------------------------------------
 # batch objective, L-BFGS
 # ------------------------------------------------------------------------------------------------
