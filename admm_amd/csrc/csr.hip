@@ -1435,7 +1435,7 @@ static void free_csr(admm_csr *c) {
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol,
                   c->d_fcol,   c->d_frow, c->d_fval, c->d_fptr, c->d_hcol, c->d_hval, c->d_hbase, c->d_hfirst,
-                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst, c->d_hmaskT, c->d_touch, c->d_touch_ptr};
+                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst, c->d_hmaskT, c->d_touch, c->d_touch_ptr, c->d_mpart};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;

@@ -188,6 +188,7 @@ struct admm_csr {
   // per-coordinate accumulators of the transposed sweep: 64-bit fixed point (value * 2^fx_shift),
   // so that sums are exact integer adds (order-independent, reproducible)
   long long *d_g1 = nullptr, *d_g2 = nullptr;
+  long long *d_mpart = nullptr;  // mini-batch FTRL: the mask columns' two sums, spread over a few copies by the forward sweep
   int fx_shift = 40;
   float vmax = 1.0f;  // max |val| of the set
 };

@@ -615,6 +615,27 @@ constexpr int kRpThreads = kHpLanes;
 
 __device__ inline unsigned long long rp_to_fx(float x, float scale) { return (unsigned long long)(long long)(x * scale); }
 
+// sum of a 64-bit value over the 16 lanes of a DPP row (row_ror by 8, 4, 2, 1); every lane gets the total
+__device__ inline long long row16_sum(long long x) {
+#define ROW16_STEP(CTRL)                                                                                      \
+  {                                                                                                           \
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)x, CTRL, 0xF, 0xF, false);     \
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)x >> 32), CTRL, 0xF, 0xF, false); \
+    x += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);                                \
+  }
+  ROW16_STEP(0x128)
+  ROW16_STEP(0x124)
+  ROW16_STEP(0x122)
+  ROW16_STEP(0x121)
+#undef ROW16_STEP
+  return x;
+}
+
+// mini-batch FTRL: a batch is one short panel per workgroup, and a few hundred workgroups adding to the
+// same kMaskCols global words at once take turns (9 of the kernel's 32 microseconds); they are spread
+// over this many copies of those words, which the per-coordinate pass adds up and clears
+constexpr int kMaskSlots = 16;
+
 struct RpArgs {
   const uint16_t *hcol;    // hot stream (ids below nhot; bit 15: last entry of its row)
   const float *hval;
@@ -640,6 +661,7 @@ struct RpArgs {
   double *partials;
   unsigned long long *g1;  // X^T r of the mask columns goes here (fixed point, gscale), nullptr: not wanted
   unsigned long long *g2;  // FTRL form: the sums of the squared gradients of those columns
+  unsigned long long *mpart;  // FTRL form: [kMaskSlots][2][kMaskCols] sums by workgroup index mod kMaskSlots, instead of adds to g1 / g2
   float gscale;
   uint64_t panel0, pcount; // panels [panel0, panel0 + pcount) are swept by this launch
 };
@@ -906,7 +928,10 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   }
   static_assert(kWarmWords == 3, "the walk above names three words");
   if (colsums) {
-    // D of block m: this lane holds column 16 m + 4 (lane >> 4) + i, digit lane & 15, in element i
+    // D of block m: this lane holds column 16 m + 4 (lane >> 4) + i, digit lane & 15, in element i.  The
+    // 16 digit lanes of a column are one DPP row: they are put together there, and one lane adds the
+    // column's sum to the workgroup's accumulator (sixteen lanes adding to one LDS word at once take
+    // turns at a full atomic's latency each).
     const int digit = lane & 15;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -914,17 +939,26 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
       for (int i = 0; i < 4; ++i) {
         const long long v = cacc[m][i];
         const int col = 16 * m + 4 * (lane >> 4) + i;
-        if (digit < 6) {
-          if (v) atomicAdd(&wacc[col], (unsigned long long)(v << (7 * digit)));
-        } else if (digit == 6) {
-          if (v) atomicAdd(&wacc[col], (unsigned long long)(-(v << 41)));
-        } else if (MODE == FWD_FTRL && digit < 13) {
-          if (v) atomicAdd(&wacc2[col], (unsigned long long)(v << (7 * (digit - 7))));
+        long long x = digit < 6 ? (v << (7 * digit)) : (digit == 6 ? -(v << 41) : 0ll);
+        x = row16_sum(x);
+        if (digit == 0 && x) atomicAdd(&wacc[col], (unsigned long long)x);
+        if (MODE == FWD_FTRL) {
+          long long x2 = (digit > 6 && digit < 13) ? (v << (7 * (digit - 7))) : 0ll;
+          x2 = row16_sum(x2);
+          if (digit == 0 && x2) atomicAdd(&wacc2[col], (unsigned long long)x2);
         }
       }
     __syncthreads();
-    if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.g1 + a.perm[tid], wacc[tid]);
-    if (MODE == FWD_FTRL && tid < (int)kMaskCols && wacc2[tid]) atomicAdd(a.g2 + a.perm[tid], wacc2[tid]);
+    if (MODE == FWD_FTRL && a.mpart) {
+      if (tid < (int)kMaskCols) {
+        unsigned long long *slot = a.mpart + (size_t)(blockIdx.x % kMaskSlots) * 2 * kMaskCols;
+        if (wacc[tid]) atomicAdd(slot + tid, wacc[tid]);
+        if (wacc2[tid]) atomicAdd(slot + kMaskCols + tid, wacc2[tid]);
+      }
+    } else {
+      if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.g1 + a.perm[tid], wacc[tid]);
+      if (MODE == FWD_FTRL && tid < (int)kMaskCols && wacc2[tid]) atomicAdd(a.g2 + a.perm[tid], wacc2[tid]);
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     acc0 += __shfl_down(acc0, off, 64);
@@ -1043,6 +1077,7 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, uint64_t r0, uint6
     if (csr->hot_dense) {
       a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
       a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
+      if (mode == FWD_FTRL) a.mpart = reinterpret_cast<unsigned long long *>(csr->d_mpart);
     }
   }
   a.panel0 = r0 / csr->fp_rows;
@@ -1411,7 +1446,11 @@ __global__ void __launch_bounds__(kTcLanes) k_transposed_cs(TcArgs a) {
     buf ^= 1;
   }
   __syncthreads();
-  for (uint32_t c = tid; c < a.ncols; c += kTcLanes) {
+  // every workgroup adds its sums to the same ncols global words: each starts at another column, so
+  // that they do not queue up at one word at a time
+  const uint32_t rot = (uint32_t)(((uint64_t)blockIdx.x * 64) % a.ncols);
+  for (uint32_t j = tid; j < a.ncols; j += kTcLanes) {
+    const uint32_t c = j + rot < a.ncols ? j + rot : j + rot - a.ncols;
     const fx_t v = cs_acc[c];
     if (v != 0) atomicAdd(&a.g1[a.perm ? a.perm[c] : c], v);
   }
@@ -1835,15 +1874,30 @@ __global__ void __launch_bounds__(256) k_ftrl_apply(long long *__restrict__ g1, 
                                                     float *__restrict__ w, float *__restrict__ z,
                                                     float *__restrict__ n, float alpha, float beta, float l1, float l2,
                                                     const double *__restrict__ partials, int bias_blocks,
-                                                    uint64_t count, const uint32_t *__restrict__ list) {
+                                                    uint64_t count, const uint32_t *__restrict__ list,
+                                                    long long *__restrict__ mpart, const uint32_t *__restrict__ inv) {
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < count; t += stride) {
     const uint64_t i = list ? list[t] : t;
-    const long long q2 = g2[i];
+    long long q1 = g1[i], q2 = g2[i];
+    if (mpart) {
+      // a column the row masks hold: the forward sweep spread its sums over kMaskSlots copies
+      const uint32_t sid = inv ? inv[i] : (uint32_t)i;
+      if (sid < kMaskCols) {
+#pragma unroll
+        for (int b = 0; b < kMaskSlots; ++b) {
+          long long *slot = mpart + (size_t)b * 2 * kMaskCols;
+          q1 += slot[sid];
+          q2 += slot[kMaskCols + sid];
+          slot[sid] = 0;
+          slot[kMaskCols + sid] = 0;
+        }
+      }
+    }
     bool touched = q2 != 0;
     double G1 = 0, G2 = 0;
     if (touched) {
-      G1 = (double)g1[i] * inv_scale;
+      G1 = (double)q1 * inv_scale;
       G2 = (double)q2 * inv_scale;
     }
     if (bias_blocks && i == 0) {
@@ -1901,6 +1955,10 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
   // columns no batch stores are never read: they only have to hold finite numbers
   ADMM_HIP_CHECK(hipMemsetAsync(csr->d_wsum, 0, sizeof(float) * csr->dim, ctx->stream));
   const bool lists = csr->d_touch != nullptr && csr->h_touch_ptr.size() == csr->npanels + 1;
+  if (csr->hot_dense && csr->has_fp && !csr->d_mpart) {
+    ADMM_HIP_CHECK(hipMalloc(&csr->d_mpart, sizeof(long long) * 2 * kMaskCols * kMaskSlots));
+    ADMM_HIP_CHECK(hipMemsetAsync(csr->d_mpart, 0, sizeof(long long) * 2 * kMaskCols * kMaskSlots, ctx->stream));
+  }
   for (uint64_t p = 0; p < csr->npanels; ++p) {
     const uint64_t r0 = p * csr->panel_rows, r1 = std::min(csr->nrows, r0 + csr->panel_rows);
     // the per-coordinate passes visit the columns this batch stores (a list kept with the copy), or all
@@ -1915,12 +1973,16 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
     }
     int nblk = 0;
     ADMM_TRY(launch_forward(csr, FWD_FTRL, r0, r1, nullptr, 0, csr->d_rowbuf, &nblk));
+    // (the sweep over the row-panel copy leaves the mask columns' sums per workgroup; the row-major one adds them itself)
+    const bool mpart_used = csr->d_mpart && csr->hot_dense && csr->has_fp && r0 % csr->fp_rows == 0 &&
+                            (r1 % csr->fp_rows == 0 || r1 == csr->nrows);
     ADMM_TRY(launch_transposed(csr, true, p, p + 1));
     {
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
       hipLaunchKernelGGL(k_ftrl_apply, dim3(grid_for(std::max<uint64_t>(count, 1), 256, ctx->cu_count * 8)), dim3(256), 0,
                          ctx->stream, csr->d_g1, csr->d_g2, std::ldexp(1.0, -csr->fx_shift), reg_offset, w, z, n, alpha, beta,
-                         l1, l2, ctx->d_partials, bias_partials ? nblk : 0, count, list);
+                         l1, l2, ctx->d_partials, bias_partials ? nblk : 0, count, list,
+                         mpart_used ? csr->d_mpart : nullptr, csr->d_inv);
       ADMM_HIP_CHECK(hipGetLastError());
     }
   }
