@@ -1014,126 +1014,6 @@ static int sort_cells(admm_csr *csr) {
   return ADMM_OK;
 }
 
-// ---- per-panel lists of stored columns (mini-batch copies) --------------------------------------
-//
-// A batch of the mini-batch FTRL pass changes only the coordinates some row of the batch stores.
-// Their list per panel is a property of the data: a bitmap over the columns is filled from the
-// panel's cells (+ the columns held by the row masks, which the cells leave out, + the bias column),
-// then compacted in ascending order.
-
-__global__ void __launch_bounds__(256) k_touch_mark(const uint64_t *__restrict__ tptr, const uint16_t *__restrict__ tcol,
-                                                    uint64_t first_cell, uint32_t col_block, uint32_t *__restrict__ bitmap) {
-  extern __shared__ uint32_t tm_sh[];  // col_block / 32 words
-  const uint32_t words = col_block / 32, b = blockIdx.x;
-  for (uint32_t i = threadIdx.x; i < words; i += 256) tm_sh[i] = 0;
-  __syncthreads();
-  for (uint64_t k = tptr[first_cell + b] + threadIdx.x, e = tptr[first_cell + b + 1]; k < e; k += 256) {
-    const uint32_t c = tcol[k];
-    atomicOr(&tm_sh[c >> 5], 1u << (c & 31u));
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < words; i += 256) bitmap[(uint64_t)b * words + i] = tm_sh[i];
-}
-
-// the columns every panel touches whatever its cells hold: the mask tier's (a relabelled set with
-// masks: `extra` = their ids in the caller's numbering) or just the bias column
-__global__ void __launch_bounds__(256) k_touch_extra(const uint32_t *__restrict__ extra, uint32_t nextra, int bias,
-                                                     uint32_t *__restrict__ bitmap) {
-  const uint32_t i = threadIdx.x;
-  if (i < nextra) atomicOr(&bitmap[extra[i] >> 5], 1u << (extra[i] & 31u));
-  if (bias && i == 0) atomicOr(&bitmap[0], 1u);
-}
-
-__global__ void __launch_bounds__(256) k_touch_count(const uint32_t *__restrict__ bitmap, uint64_t words,
-                                                     uint32_t *__restrict__ counts) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) counts[i] = __popc(bitmap[i]);
-}
-
-__global__ void __launch_bounds__(256) k_touch_emit(const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ start,
-                                                    uint64_t words, uint32_t *__restrict__ out) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) {
-    uint32_t m = bitmap[i], at = start[i];
-    while (m) {
-      out[at++] = (uint32_t)(i * 32) + (uint32_t)__builtin_ctz(m);
-      m &= m - 1;
-    }
-  }
-}
-
-int build_touched(admm_csr *csr) {
-  admm_ctx *ctx = csr->ctx;
-  for (void **q : {(void **)&csr->d_touch, (void **)&csr->d_touch_ptr}) {
-    if (*q) hipFree(*q);
-    *q = nullptr;
-  }
-  csr->h_touch_ptr.clear();
-  if (!csr->has_t || !csr->t_named || csr->npanels == 0) return ADMM_OK;
-  const uint64_t padded = (uint64_t)csr->nblocks * csr->col_block, words = padded / 32;
-  uint32_t *bitmap = nullptr, *counts = nullptr, *starts = nullptr, *totals = nullptr;
-  void *tmp = nullptr;
-  size_t tmp_bytes = 0;
-  auto cleanup = [&]() {
-    for (void *q : {(void *)bitmap, (void *)counts, (void *)starts, (void *)totals, tmp})
-      if (q) hipFree(q);
-  };
-#define BT_CHECK(expr)                                                             \
-  do {                                                                             \
-    hipError_t e_ = (expr);                                                        \
-    if (e_ != hipSuccess) {                                                        \
-      set_error("admm_csr_build_transposed (column lists): %s: %s", #expr, hipGetErrorString(e_)); \
-      cleanup();                                                                   \
-      return e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP;            \
-    }                                                                              \
-  } while (0)
-  BT_CHECK(hipMalloc(&bitmap, sizeof(uint32_t) * words));
-  BT_CHECK(hipMalloc(&counts, sizeof(uint32_t) * (words + 1)));
-  BT_CHECK(hipMalloc(&starts, sizeof(uint32_t) * (words + 1)));
-  BT_CHECK(hipMalloc(&totals, sizeof(uint32_t) * csr->npanels));
-  BT_CHECK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * (words + 1), ctx->stream));
-  BT_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, counts, starts, (int64_t)(words + 1), ctx->stream));
-  BT_CHECK(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-  const uint32_t nextra = csr->hot_dense ? kMaskCols : 0;
-  const int bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
-  const int wgrid = grid_for(words, 256, ctx->cu_count * 8);
-  auto mark = [&](uint64_t p) {
-    hipLaunchKernelGGL(k_touch_mark, dim3(csr->nblocks), dim3(256), sizeof(uint32_t) * (csr->col_block / 32), ctx->stream,
-                       csr->d_tptr, csr->d_tcol, p * csr->nblocks, csr->col_block, bitmap);
-    if (nextra || bias)
-      hipLaunchKernelGGL(k_touch_extra, dim3(1), dim3(256), 0, ctx->stream, csr->d_perm, nextra, bias, bitmap);
-    hipLaunchKernelGGL(k_touch_count, dim3(wgrid), dim3(256), 0, ctx->stream, bitmap, words, counts);
-    size_t bytes = tmp_bytes;
-    return hipcub::DeviceScan::ExclusiveSum(tmp, bytes, counts, starts, (int64_t)(words + 1), ctx->stream);
-  };
-  // pass 1: sizes
-  for (uint64_t p = 0; p < csr->npanels; ++p) {
-    BT_CHECK(mark(p));
-    BT_CHECK(hipMemcpyAsync(totals + p, starts + words, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-  }
-  std::vector<uint32_t> h_tot(csr->npanels);
-  BT_CHECK(hipMemcpyAsync(h_tot.data(), totals, sizeof(uint32_t) * csr->npanels, hipMemcpyDeviceToHost, ctx->stream));
-  BT_CHECK(hipStreamSynchronize(ctx->stream));
-  csr->h_touch_ptr.assign(csr->npanels + 1, 0);
-  for (uint64_t p = 0; p < csr->npanels; ++p) csr->h_touch_ptr[p + 1] = csr->h_touch_ptr[p] + h_tot[p];
-  const uint64_t total = csr->h_touch_ptr[csr->npanels];
-  BT_CHECK(hipMalloc(&csr->d_touch, sizeof(uint32_t) * (total + 8)));
-  BT_CHECK(hipMalloc(&csr->d_touch_ptr, sizeof(uint64_t) * (csr->npanels + 1)));
-  BT_CHECK(hipMemcpyAsync(csr->d_touch_ptr, csr->h_touch_ptr.data(), sizeof(uint64_t) * (csr->npanels + 1),
-                          hipMemcpyHostToDevice, ctx->stream));
-  // pass 2: the lists
-  for (uint64_t p = 0; p < csr->npanels; ++p) {
-    BT_CHECK(mark(p));
-    hipLaunchKernelGGL(k_touch_emit, dim3(wgrid), dim3(256), 0, ctx->stream, bitmap, starts, words,
-                       csr->d_touch + csr->h_touch_ptr[p]);
-    BT_CHECK(hipGetLastError());
-  }
-  BT_CHECK(hipStreamSynchronize(ctx->stream));
-#undef BT_CHECK
-  cleanup();
-  return ADMM_OK;
-}
-
 // ---- previous-occurrence table of the sequential FTRL pass -------------------------------------
 //
 // dep[k] = (rows back << 16) | position in that row, of the last earlier row that stores entry k's
@@ -1435,7 +1315,7 @@ static void free_csr(admm_csr *c) {
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol,
                   c->d_fcol,   c->d_frow, c->d_fval, c->d_fptr, c->d_hcol, c->d_hval, c->d_hbase, c->d_hfirst,
-                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst, c->d_hmaskT, c->d_touch, c->d_touch_ptr, c->d_mpart};
+                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst, c->d_hmaskT, c->d_mpart};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;
@@ -1851,7 +1731,6 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   csr->fx_shift = std::max(8, std::min(50 - 13, 61 - need) - vbits);
   csr->has_t = true;
   ADMM_TRY(ensure_taccum(csr));
-  ADMM_TRY(build_touched(csr));
   ADMM_TRY(build_forward_panels(csr));
   return ADMM_OK;
 }

@@ -135,11 +135,6 @@ struct admm_csr {
   // transposed (column-block) copy
   bool has_t = false;
   bool t_named = false;  // the caller named the panel size: the copy serves sweeps over panel ranges (mini-batches)
-  // mini-batch copies: per panel, the columns (caller's ids, ascending) that some row of the panel stores --
-  // what a batch's per-coordinate passes have to visit; d_touch_ptr[npanels + 1] indexes d_touch
-  uint32_t *d_touch = nullptr;
-  uint64_t *d_touch_ptr = nullptr;
-  std::vector<uint64_t> h_touch_ptr;
   uint64_t panel_rows = 0;
   uint32_t col_block = 0, nblocks = 0;
   uint64_t npanels = 0, tnnz = 0;
@@ -215,7 +210,6 @@ int finish_partials(admm_ctx *ctx, int nscalars, int nblocks);
 
 int ensure_rowbuf(admm_csr *csr);
 int build_forward_panels(admm_csr *csr);  // csr.hip
-int build_touched(admm_csr *csr);         // csr.hip: per-panel lists of stored columns (mini-batch copies)
 int build_dep(admm_csr *csr);             // csr.hip: previous-occurrence table of the sequential FTRL pass
 int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool column_stream);  // csr.hip
 int ensure_taccum(admm_csr *csr);

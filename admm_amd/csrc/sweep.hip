@@ -45,6 +45,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kMaskSlots = 16;  // copies of the mask columns' global sums in the mini-batch FTRL pass (see RpArgs::mpart)
+
 __device__ inline float clamp35(float m) { return fmaxf(fminf(m, 35.0f), -35.0f); }
 
 // Forward sweep geometry: one workgroup per CU, split into kFwConsumers reducing threads and
@@ -633,9 +635,7 @@ __device__ inline long long row16_sum(long long x) {
 
 // mini-batch FTRL: a batch is one short panel per workgroup, and a few hundred workgroups adding to the
 // same kMaskCols global words at once take turns (9 of the kernel's 32 microseconds); they are spread
-// over this many copies of those words, which the per-coordinate pass adds up and clears
-constexpr int kMaskSlots = 16;
-
+// over kMaskSlots copies of those words, which the per-coordinate pass adds up and clears
 struct RpArgs {
   const uint16_t *hcol;    // hot stream (ids below nhot; bit 15: last entry of its row)
   const float *hval;
@@ -1063,7 +1063,8 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, uint64_t r0, uint6
   a.w = csr->d_wsum;
   a.nhot = csr->fp_hot;
   a.blockmax = blockmax;
-  a.nblockmax = wgrid;
+  // (the mini-batch pass keeps running maxima behind the per-workgroup ones: one per column block, one more)
+  a.nblockmax = wgrid + (mode == FWD_FTRL ? (int)csr->nblocks + 1 : 0);
   a.lenbits = csr->fp_lenbits;
   a.vmax = csr->vmax;
   a.nrows = csr->nrows;
@@ -1222,10 +1223,34 @@ struct TArgs {
   uint32_t nblocks, col_block;
   uint64_t panel0, npanels;  // panels [panel0, panel0 + npanels) are swept by this launch
   int no_gather;             // calibration runs only: skip the per-row gathers (results are then meaningless)
+  // FTRL form over one panel (= one mini-batch): fz != nullptr applies the batch's update to the
+  // cell's columns right here (the cell holds every entry the batch stores in them) instead of adding
+  // the sums to g1 / g2 for a separate pass
+  float *fw, *fz, *fn;
+  const float *freg, *foff;
+  const uint32_t *finv;      // caller's id -> stored id (nullptr: identity)
+  float *fwsum;              // the forward sweep's gathered vector (stored order), kept current column by column
+  float *fabsmax;            // [nblocks] running max |fwsum| per column block (each written by that block's workgroup only)
+  float falpha, fbeta, fl1, fl2;
+  double finv_scale;
+  long long *fmpart;         // the mask columns' sums of the forward sweep (kMaskSlots copies), nullptr: none
+  const double *fpartials;   // bias column of a set without masks: the forward sweep's per-workgroup sums
+  int fbias_blocks;
+  uint64_t fdim;
 };
 
 
 typedef unsigned long long fx_t;  // two's-complement fixed point held in an unsigned word
+
+__device__ inline float ftrl_weight(float z, float n, float c, float alpha, float beta, float l1, float l2) {
+  // src/ftrl.cc:61-66 (threshold on l1, shrink by the literal 1)
+  const float sign = z < 0.0f ? -1.0f : 1.0f;
+  if (sign * z <= l1) return 0.0f;
+  const float num = sign * 1 - z + l2 * c;
+  const double den = ((double)beta + sqrt((double)n)) / (double)alpha + (double)l2;
+  return (float)((double)num / den);
+}
+
 
 __device__ inline fx_t to_fx(float x, float scale) { return (fx_t)(long long)(x * scale); }
 
@@ -1263,7 +1288,8 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
   const uint32_t blk = (uint32_t)((grouped ? slot : (uint64_t)blockIdx.x) % a.nblocks);
   const uint64_t cell = (a.panel0 + plocal) * a.nblocks + blk;
   const uint64_t beg = a.tptr[cell], end = a.tptr[cell + 1];
-  if (beg == end) return;
+  const bool fused = FTRL && a.fz != nullptr;
+  if (beg == end && !fused) return;  // (fused: the cell's columns may still have sums waiting from the row masks)
   const uint32_t CB = a.col_block;
   fx_t *acc2 = acc + CB;
   const float scale = a.scale;
@@ -1332,6 +1358,66 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
   }
   __syncthreads();
   const uint64_t gbase = (uint64_t)blk * CB;
+  if (fused) {
+    // the batch's update of this cell's columns (src/ftrl.cc:76-88 summed over the batch's rows):
+    // w <- the lazy weight at the batch's start, n' = n + G2, z += G1 - w (sqrt(n') - sqrt(n)) / alpha;
+    // then the column's entry of the forward sweep's vector is brought up to date
+    float vmax = 0.0f;
+    for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
+      const uint64_t i = gbase + c;
+      if (i >= a.fdim) continue;
+      long long q1 = (long long)acc[c], q2 = (long long)acc2[c];
+      const uint32_t sid = a.finv ? a.finv[i] : (uint32_t)i;
+      if (a.fmpart && sid < kMaskCols) {
+#pragma unroll
+        for (int b = 0; b < kMaskSlots; ++b) {
+          long long *slot = a.fmpart + (size_t)b * 2 * kMaskCols;
+          q1 += slot[sid];
+          q2 += slot[kMaskCols + sid];
+          slot[sid] = 0;
+          slot[kMaskCols + sid] = 0;
+        }
+      }
+      bool touched = q2 != 0;
+      double G1 = 0, G2 = 0;
+      if (touched) {
+        G1 = (double)q1 * a.finv_scale;
+        G2 = (double)q2 * a.finv_scale;
+      }
+      if (a.fbias_blocks && i == 0) {
+        touched = true;
+        for (int b = 0; b < a.fbias_blocks; ++b) {
+          G1 += a.fpartials[0 * kMaxPartialBlocks + b];
+          G2 += a.fpartials[1 * kMaxPartialBlocks + b];
+        }
+      }
+      if (touched) {
+        const float nold = a.fn[i], zold = a.fz[i], reg = a.freg[i];
+        const float wc = ftrl_weight(zold, nold, reg, a.falpha, a.fbeta, a.fl1, a.fl2);
+        const float nnew = (float)((double)nold + G2);
+        const double sigma = (sqrt((double)nnew) - sqrt((double)nold)) / (double)a.falpha;
+        const float znew = (float)((double)zold + (G1 - sigma * (double)wc));
+        a.fw[i] = wc;
+        a.fz[i] = znew;
+        a.fn[i] = nnew;
+        const float v = ftrl_weight(znew, nnew, reg, a.falpha, a.fbeta, a.fl1, a.fl2) + a.foff[i];
+        a.fwsum[sid] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+    // the block's running maximum (no other workgroup writes it in this launch)
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    __syncthreads();  // the accumulators are read: their first words now carry the waves' maxima
+    float *wmax = reinterpret_cast<float *>(acc);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = a.fabsmax[blk];
+      for (int w8 = 0; w8 < kTThreads / 64; ++w8) m = fmaxf(m, wmax[w8]);
+      a.fabsmax[blk] = m;
+    }
+    return;
+  }
   for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
     const fx_t s = acc[c];
     if (FTRL) {
@@ -1485,13 +1571,24 @@ static int launch_column_stream(admm_csr *csr) {
   return ADMM_OK;
 }
 
+static int launch_transposed_impl(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1, const TArgs *fuse);
+
 int launch_transposed(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1) {
+  return launch_transposed_impl(csr, ftrl_mode, p0, p1, nullptr);
+}
+
+// fuse: the f* fields of a mini-batch's fused update (FTRL form, one panel), or nullptr
+static int launch_transposed_impl(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1, const TArgs *fuse) {
   admm_ctx *ctx = csr->ctx;
   ADMM_REQUIRE(csr->has_t, "transposed sweep: call admm_csr_build_transposed first");
   if (p0 >= p1) return ADMM_OK;
   ADMM_REQUIRE(!csr->has_tc || (!ftrl_mode && p0 == 0 && p1 == csr->npanels),
                "transposed sweep: a copy with a column stream serves whole-set sweeps only");
   TArgs a{};
+  if (fuse) {
+    ADMM_REQUIRE(ftrl_mode && p1 == p0 + 1, "transposed sweep: the fused update takes one panel in the FTRL form");
+    a = *fuse;
+  }
   a.tptr = csr->d_tptr;
   a.trow = csr->d_trow;
   a.tcol = csr->d_tcol;
@@ -1834,14 +1931,6 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
 // mini-batch FTRL
 // ---------------------------------------------------------------------------------------------
 
-__device__ inline float ftrl_weight(float z, float n, float c, float alpha, float beta, float l1, float l2) {
-  // src/ftrl.cc:61-66 (threshold on l1, shrink by the literal 1)
-  const float sign = z < 0.0f ? -1.0f : 1.0f;
-  if (sign * z <= l1) return 0.0f;
-  const float num = sign * 1 - z + l2 * c;
-  const double den = ((double)beta + sqrt((double)n)) / (double)alpha + (double)l2;
-  return (float)((double)num / den);
-}
 
 // The vector the forward sweep of a batch gathers: lazy weight at the batch's start plus offset, in
 // the sample set's stored column order.  The state is read in its own order (coalesced) and the
@@ -1849,13 +1938,12 @@ __device__ inline float ftrl_weight(float z, float n, float c, float alpha, floa
 __global__ void __launch_bounds__(256) k_ftrl_wsum(const float *__restrict__ z, const float *__restrict__ n,
                                                    const float *__restrict__ c, const float *__restrict__ offset,
                                                    const uint32_t *__restrict__ inv, float alpha, float beta, float l1,
-                                                   float l2, float *__restrict__ wsum, uint64_t count,
-                                                   const uint32_t *__restrict__ list, float *__restrict__ blockmax) {
+                                                   float l2, float *__restrict__ wsum, uint64_t dim,
+                                                   float *__restrict__ blockmax) {
   __shared__ float sh[4];
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   float m = 0.0f;
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < count; t += stride) {
-    const uint64_t i = list ? list[t] : t;  // list: the columns the batch stores (no other weight is read)
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
     const float v = ftrl_weight(z[i], n[i], c[i], alpha, beta, l1, l2) + offset[i];
     wsum[inv ? inv[i] : i] = v;
     m = fmaxf(m, fabsf(v));
@@ -1866,43 +1954,29 @@ __global__ void __launch_bounds__(256) k_ftrl_wsum(const float *__restrict__ z, 
   if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));  // for the sweep's fixed-point shift
 }
 
-// per coordinate touched in the batch (its squared-gradient sum is non-zero): w <- the lazy weight at
-// the batch's start (recomputed here: same inputs, same arithmetic as in k_ftrl_wsum), n' = n + G2,
-// z += G1 - w (sqrt(n') - sqrt(n)) / alpha ; the accumulators are cleared
+// Fallback of the fused update in the transposed sweep, for a batch whose forward sweep ran over the
+// row-major form (it adds the mask columns' sums to g1 / g2): per coordinate touched in the batch (its
+// squared-gradient sum is non-zero) w <- the lazy weight at the batch's start, n' = n + G2,
+// z += G1 - w (sqrt(n') - sqrt(n)) / alpha; the accumulators are cleared and the column's entry of the
+// forward sweep's vector is brought up to date
 __global__ void __launch_bounds__(256) k_ftrl_apply(long long *__restrict__ g1, long long *__restrict__ g2,
                                                     double inv_scale, const float *__restrict__ c,
-                                                    float *__restrict__ w, float *__restrict__ z,
-                                                    float *__restrict__ n, float alpha, float beta, float l1, float l2,
-                                                    const double *__restrict__ partials, int bias_blocks,
-                                                    uint64_t count, const uint32_t *__restrict__ list,
-                                                    long long *__restrict__ mpart, const uint32_t *__restrict__ inv) {
+                                                    const float *__restrict__ offset, float *__restrict__ w,
+                                                    float *__restrict__ z, float *__restrict__ n, float alpha, float beta,
+                                                    float l1, float l2, const double *__restrict__ partials, int bias_blocks,
+                                                    uint64_t dim, const uint32_t *__restrict__ inv, float *__restrict__ wsum,
+                                                    unsigned int *__restrict__ absmax) {
   const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < count; t += stride) {
-    const uint64_t i = list ? list[t] : t;
-    long long q1 = g1[i], q2 = g2[i];
-    if (mpart) {
-      // a column the row masks hold: the forward sweep spread its sums over kMaskSlots copies
-      const uint32_t sid = inv ? inv[i] : (uint32_t)i;
-      if (sid < kMaskCols) {
-#pragma unroll
-        for (int b = 0; b < kMaskSlots; ++b) {
-          long long *slot = mpart + (size_t)b * 2 * kMaskCols;
-          q1 += slot[sid];
-          q2 += slot[kMaskCols + sid];
-          slot[sid] = 0;
-          slot[kMaskCols + sid] = 0;
-        }
-      }
-    }
+  float vmax = 0.0f;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
+    const long long q2 = g2[i];
     bool touched = q2 != 0;
     double G1 = 0, G2 = 0;
     if (touched) {
-      G1 = (double)q1 * inv_scale;
+      G1 = (double)g1[i] * inv_scale;
       G2 = (double)q2 * inv_scale;
     }
     if (bias_blocks && i == 0) {
-      // a set whose bias column is not held by row masks: the forward sweep left the column's sums as
-      // per-workgroup partials (rows 0 and 1), added here in a fixed order
       touched = true;
       for (int b = 0; b < bias_blocks; ++b) {
         G1 += partials[0 * kMaxPartialBlocks + b];
@@ -1914,13 +1988,19 @@ __global__ void __launch_bounds__(256) k_ftrl_apply(long long *__restrict__ g1, 
       const float wc = ftrl_weight(zold, nold, c[i], alpha, beta, l1, l2);
       const float nnew = (float)((double)nold + G2);
       const double sigma = (sqrt((double)nnew) - sqrt((double)nold)) / (double)alpha;
+      const float znew = (float)((double)zold + (G1 - sigma * (double)wc));
       w[i] = wc;
-      z[i] = (float)((double)zold + (G1 - sigma * (double)wc));
+      z[i] = znew;
       n[i] = nnew;
       g1[i] = 0;
       g2[i] = 0;
+      const float v = ftrl_weight(znew, nnew, c[i], alpha, beta, l1, l2) + offset[i];
+      wsum[inv ? inv[i] : i] = v;
+      vmax = fmaxf(vmax, fabsf(v));
     }
   }
+  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(absmax, __float_as_uint(vmax));  // non-negative floats order like their bits
 }
 
 // the trailing Predict of FtrlSolver::Run on the last row (src/ftrl.cc:140-141): refresh the
@@ -1952,39 +2032,62 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
   ADMM_TRY(ensure_rowbuf(csr));
   if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
   const bool bias_partials = csr->has_bias && !csr->hot_dense;
-  // columns no batch stores are never read: they only have to hold finite numbers
-  ADMM_HIP_CHECK(hipMemsetAsync(csr->d_wsum, 0, sizeof(float) * csr->dim, ctx->stream));
-  const bool lists = csr->d_touch != nullptr && csr->h_touch_ptr.size() == csr->npanels + 1;
   if (csr->hot_dense && csr->has_fp && !csr->d_mpart) {
     ADMM_HIP_CHECK(hipMalloc(&csr->d_mpart, sizeof(long long) * 2 * kMaskCols * kMaskSlots));
     ADMM_HIP_CHECK(hipMemsetAsync(csr->d_mpart, 0, sizeof(long long) * 2 * kMaskCols * kMaskSlots, ctx->stream));
   }
+  // The vector the forward sweeps gather (lazy weight + offset per column, stored order) is computed
+  // once for all columns; after that a column's entry changes only when a batch updates the column,
+  // and the update writes it.  The maxima the sweeps derive their fixed-point shift from: one per
+  // workgroup of this first pass, plus one running maximum that the updates raise.
+  const int wgrid = wsum_grid(ctx, csr->dim);
+  float *blockmax = wsum_blockmax(ctx);
+  ADMM_REQUIRE((size_t)wgrid + csr->nblocks + 1 <= 2 * (size_t)kMaxPartialBlocks * sizeof(double) / sizeof(float),
+               "admm_ftrl_pass: too many column blocks (%u)", csr->nblocks);
+  ADMM_HIP_CHECK(hipMemsetAsync(blockmax + wgrid, 0, sizeof(float) * (csr->nblocks + 1), ctx->stream));
+  {
+    KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_ftrl_wsum, dim3(wgrid), dim3(256), 0, ctx->stream, z, n, reg_offset, offset, csr->d_inv, alpha, beta,
+                       l1, l2, csr->d_wsum, csr->dim, blockmax);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  TArgs fuse{};
+  fuse.fw = w;
+  fuse.fz = z;
+  fuse.fn = n;
+  fuse.freg = reg_offset;
+  fuse.foff = offset;
+  fuse.finv = csr->d_inv;
+  fuse.fwsum = csr->d_wsum;
+  fuse.fabsmax = blockmax + wgrid;
+  fuse.falpha = alpha;
+  fuse.fbeta = beta;
+  fuse.fl1 = l1;
+  fuse.fl2 = l2;
+  fuse.finv_scale = std::ldexp(1.0, -csr->fx_shift);
+  fuse.fpartials = ctx->d_partials;
+  fuse.fdim = csr->dim;
   for (uint64_t p = 0; p < csr->npanels; ++p) {
     const uint64_t r0 = p * csr->panel_rows, r1 = std::min(csr->nrows, r0 + csr->panel_rows);
-    // the per-coordinate passes visit the columns this batch stores (a list kept with the copy), or all
-    const uint64_t count = lists ? csr->h_touch_ptr[p + 1] - csr->h_touch_ptr[p] : csr->dim;
-    const uint32_t *list = lists ? csr->d_touch + csr->h_touch_ptr[p] : nullptr;
-    {
-      KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
-      // every workgroup of the full-size grid leaves a maximum: launch that grid (idle ones write 0)
-      hipLaunchKernelGGL(k_ftrl_wsum, dim3(wsum_grid(ctx, csr->dim)), dim3(256), 0, ctx->stream, z, n, reg_offset, offset,
-                         csr->d_inv, alpha, beta, l1, l2, csr->d_wsum, count, list, wsum_blockmax(ctx));
-      ADMM_HIP_CHECK(hipGetLastError());
-    }
     int nblk = 0;
     ADMM_TRY(launch_forward(csr, FWD_FTRL, r0, r1, nullptr, 0, csr->d_rowbuf, &nblk));
-    // (the sweep over the row-panel copy leaves the mask columns' sums per workgroup; the row-major one adds them itself)
+    // (the sweep over the row-panel copy leaves the mask columns' sums in their copies; the row-major one adds them to g1 / g2 itself)
     const bool mpart_used = csr->d_mpart && csr->hot_dense && csr->has_fp && r0 % csr->fp_rows == 0 &&
                             (r1 % csr->fp_rows == 0 || r1 == csr->nrows);
-    ADMM_TRY(launch_transposed(csr, true, p, p + 1));
-    {
+    if (csr->hot_dense && !mpart_used) {
+      // mask columns' sums sit in g1 / g2: the separate per-coordinate pass reads them there
+      ADMM_TRY(launch_transposed(csr, true, p, p + 1));
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
-      hipLaunchKernelGGL(k_ftrl_apply, dim3(grid_for(std::max<uint64_t>(count, 1), 256, ctx->cu_count * 8)), dim3(256), 0,
-                         ctx->stream, csr->d_g1, csr->d_g2, std::ldexp(1.0, -csr->fx_shift), reg_offset, w, z, n, alpha, beta,
-                         l1, l2, ctx->d_partials, bias_partials ? nblk : 0, count, list,
-                         mpart_used ? csr->d_mpart : nullptr, csr->d_inv);
+      hipLaunchKernelGGL(k_ftrl_apply, dim3(grid_for(csr->dim, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, csr->d_g1,
+                         csr->d_g2, std::ldexp(1.0, -csr->fx_shift), reg_offset, offset, w, z, n, alpha, beta, l1, l2,
+                         ctx->d_partials, 0, csr->dim, csr->d_inv, csr->d_wsum,
+                         reinterpret_cast<unsigned int *>(blockmax + wgrid + csr->nblocks));
       ADMM_HIP_CHECK(hipGetLastError());
+      continue;
     }
+    fuse.fmpart = mpart_used ? csr->d_mpart : nullptr;
+    fuse.fbias_blocks = bias_partials ? nblk : 0;
+    ADMM_TRY(launch_transposed_impl(csr, true, p, p + 1, &fuse));
   }
   if (csr->nrows) {
     hipLaunchKernelGGL(k_ftrl_last_row, dim3(1), dim3(64), 0, ctx->stream, csr->d_rowptr, csr->d_col,
