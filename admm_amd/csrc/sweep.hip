@@ -982,21 +982,22 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   }
 }
 
-// wsum (see k_wsum), plus the largest |wsum| per workgroup
+// wsum (see k_wsum), plus the largest |wsum| per workgroup.  The vectors are read in the caller's
+// order (coalesced) and the sum goes to the column's stored position (inv: caller's id -> stored id;
+// nullptr: identity): a scattered 4-byte store is cheaper than two or more scattered loads.
 __global__ void __launch_bounds__(256) k_wsum_absmax(const float *__restrict__ w0, const float *__restrict__ w1,
                                                      const float *__restrict__ w2, const float *__restrict__ w3,
-                                                     const uint32_t *__restrict__ perm, float *__restrict__ wsum,
+                                                     const uint32_t *__restrict__ inv, float *__restrict__ wsum,
                                                      uint64_t dim, float *__restrict__ blockmax) {
   __shared__ float sh[4];
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   float m = 0.0f;
-  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < dim; j += stride) {
-    const uint64_t o = perm ? perm[j] : j;
-    float s = w0[o];
-    if (w1) s += w1[o];
-    if (w2) s += w2[o];
-    if (w3) s += w3[o];
-    wsum[j] = s;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
+    float s = w0[i];
+    if (w1) s += w1[i];
+    if (w2) s += w2[i];
+    if (w3) s += w3[i];
+    wsum[inv ? inv[i] : i] = s;
     const float av = fabsf(s);
     m = av > m ? av : m;  // a NaN weight is not seen here: it reaches the margins through to_fx as garbage
   }
@@ -1040,7 +1041,7 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, uint64_t r0, uint6
   if (nw > 0) {
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_wsum_absmax, dim3(wgrid), dim3(256), 0, ctx->stream, w[0], nw > 1 ? w[1] : nullptr,
-                       nw > 2 ? w[2] : nullptr, nw > 3 ? w[3] : nullptr, csr->d_perm, csr->d_wsum, csr->dim, blockmax);
+                       nw > 2 ? w[2] : nullptr, nw > 3 ? w[3] : nullptr, csr->d_inv, csr->d_wsum, csr->dim, blockmax);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   RpArgs a{};
