@@ -778,22 +778,35 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         }
       };
       uint32_t q = 0;
-      for (; q + 2 <= nq; q += 2) {
-        const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kRpThreads);
-        const u32x2 c1 = __builtin_nontemporal_load(src + (uint64_t)(q + 1) * kRpThreads);
-        f32x4 v0 = {1.f, 1.f, 1.f, 1.f}, v1 = v0;
-        if (HASVAL) {
-          v0 = __builtin_nontemporal_load(vsrc + (uint64_t)q * kRpThreads);
-          v1 = __builtin_nontemporal_load(vsrc + (uint64_t)(q + 1) * kRpThreads);
+      // four groups of four words per trip, the next trip's loads issued before this trip's work: a wave
+      // otherwise has nothing in flight while it adds
+      constexpr int kAhead = 4;
+      u32x2 nx[kAhead];
+      f32x4 nv[kAhead];
+      auto fetch = [&](uint32_t at) {
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+          nx[j] = __builtin_nontemporal_load(src + (uint64_t)(at + j) * kRpThreads);
+          if (HASVAL) nv[j] = __builtin_nontemporal_load(vsrc + (uint64_t)(at + j) * kRpThreads);
         }
-        step(c0.x & 0xFFFFu, v0.x);
-        step(c0.x >> 16, v0.y);
-        step(c0.y & 0xFFFFu, v0.z);
-        step(c0.y >> 16, v0.w);
-        step(c1.x & 0xFFFFu, v1.x);
-        step(c1.x >> 16, v1.y);
-        step(c1.y & 0xFFFFu, v1.z);
-        step(c1.y >> 16, v1.w);
+      };
+      if (nq >= kAhead) fetch(0);
+      for (; q + kAhead <= nq; q += kAhead) {
+        u32x2 cx[kAhead];
+        f32x4 cv[kAhead];
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+          cx[j] = nx[j];
+          cv[j] = HASVAL ? nv[j] : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+        if (q + 2 * kAhead <= nq) fetch(q + kAhead);
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+          step(cx[j].x & 0xFFFFu, cv[j].x);
+          step(cx[j].x >> 16, cv[j].y);
+          step(cx[j].y & 0xFFFFu, cv[j].z);
+          step(cx[j].y >> 16, cv[j].w);
+        }
       }
       for (; q < nq; ++q) {
         const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kRpThreads);
@@ -1502,22 +1515,35 @@ __global__ void __launch_bounds__(kTcLanes) k_transposed_cs(TcArgs a) {
       }
     };
     uint32_t q = 0;
-    for (; q + 2 <= nq; q += 2) {
-      const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kTcLanes);
-      const u32x2 c1 = __builtin_nontemporal_load(src + (uint64_t)(q + 1) * kTcLanes);
-      f32x4 v0 = {1.f, 1.f, 1.f, 1.f}, v1 = v0;
-      if (HASVAL) {
-        v0 = __builtin_nontemporal_load(vsrc + (uint64_t)q * kTcLanes);
-        v1 = __builtin_nontemporal_load(vsrc + (uint64_t)(q + 1) * kTcLanes);
+    // four groups of four words per trip, the next trip's loads issued before this trip's work: a wave
+    // otherwise has nothing in flight while it adds
+    constexpr int kAhead = 4;
+    u32x2 nx[kAhead];
+    f32x4 nv[kAhead];
+    auto fetch = [&](uint32_t at) {
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+        nx[j] = __builtin_nontemporal_load(src + (uint64_t)(at + j) * kTcLanes);
+        if (HASVAL) nv[j] = __builtin_nontemporal_load(vsrc + (uint64_t)(at + j) * kTcLanes);
       }
-      step(c0.x & 0xFFFFu, v0.x);
-      step(c0.x >> 16, v0.y);
-      step(c0.y & 0xFFFFu, v0.z);
-      step(c0.y >> 16, v0.w);
-      step(c1.x & 0xFFFFu, v1.x);
-      step(c1.x >> 16, v1.y);
-      step(c1.y & 0xFFFFu, v1.z);
-      step(c1.y >> 16, v1.w);
+    };
+    if (nq >= kAhead) fetch(0);
+    for (; q + kAhead <= nq; q += kAhead) {
+      u32x2 cx[kAhead];
+      f32x4 cv[kAhead];
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+        cx[j] = nx[j];
+        cv[j] = HASVAL ? nv[j] : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
+      if (q + 2 * kAhead <= nq) fetch(q + kAhead);
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+        step(cx[j].x & 0xFFFFu, cv[j].x);
+        step(cx[j].x >> 16, cv[j].y);
+        step(cx[j].y & 0xFFFFu, cv[j].z);
+        step(cx[j].y >> 16, cv[j].w);
+      }
     }
     for (; q < nq; ++q) {
       const u32x2 c0 = __builtin_nontemporal_load(src + (uint64_t)q * kTcLanes);
