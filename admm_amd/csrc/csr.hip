@@ -1624,10 +1624,13 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   if (panel_rows == 0) {
     // about a million rows per panel, and a multiple of 8 panels when the set is large enough:
     // the sweep hands each of the 8 XCDs its own panels
+    // (a set of up to 13M rows gets one group of eight larger panels: 12.5M rows swept 6 % faster
+    // in 8 panels of 1.56M than in 16 of 0.78M; at 100M rows 1.04M beats 1.56M by 5 %)
     panel_rows = 1u << 20;
     if (csr->nrows > (1u << 20)) {
+      const uint64_t limit = csr->nrows <= 13000000ull ? 1625000ull : (1ull << 20);
       uint64_t groups = 1;
-      while ((csr->nrows + 8 * groups - 1) / (8 * groups) > (1u << 20)) ++groups;
+      while ((csr->nrows + 8 * groups - 1) / (8 * groups) > limit) ++groups;
       panel_rows = (csr->nrows + 8 * groups - 1) / (8 * groups);
     }
   }
