@@ -738,23 +738,42 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   for (uint64_t p = a.panel0 + blockIdx.x; p < a.panel0 + a.pcount; p += gridDim.x) {
     const uint64_t r0 = p * R;
     const uint32_t nr = (uint32_t)(a.nrows - r0 < R ? a.nrows - r0 : R);
-    // ---- margins start at the mask tier's part (or at the bias weight)
-    for (uint32_t r = tid; r < nr; r += kRpThreads) {
-      float m0 = w0;
+    // ---- margins start at the mask tier's part (or at the bias weight).  A lane takes every
+    // kRpThreads-th row; the mask words of four of its rows are loaded before any of them is used
+    // (each row's work hangs on its own loads, which would otherwise be waited for one row at a time)
+    for (uint32_t rb4 = tid; rb4 < nr; rb4 += 4 * kRpThreads) {
+      unsigned long long mm[4] = {0, 0, 0, 0}, ww[4][kWarmWords] = {};
       if (dense) {
-        const unsigned long long m = a.hmask[r0 + r];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) m0 += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t r = rb4 + j * kRpThreads;
+          if (r < nr) {
+            mm[j] = a.hmask[r0 + r];
 #pragma unroll
-        for (int w = 0; w < kWarmWords; ++w) {
-          unsigned long long mw = a.hwarm[(r0 + r) * kWarmWords + w];
-          while (mw) {
-            m0 += raw[64 * (w + 1) + __builtin_ctzll(mw)];
-            mw &= mw - 1;
+            for (int w = 0; w < kWarmWords; ++w) ww[j][w] = a.hwarm[(r0 + r) * kWarmWords + w];
           }
         }
       }
-      rp_acc[r] = rp_to_fx(m0, scale);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t r = rb4 + j * kRpThreads;
+        if (r >= nr) break;
+        float m0 = w0;
+        if (dense) {
+          const unsigned long long m = mm[j];
+#pragma unroll
+          for (int g = 0; g < 8; ++g) m0 += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
+#pragma unroll
+          for (int w = 0; w < kWarmWords; ++w) {
+            unsigned long long mw = ww[j][w];
+            while (mw) {
+              m0 += raw[64 * (w + 1) + __builtin_ctzll(mw)];
+              mw &= mw - 1;
+            }
+          }
+        }
+        rp_acc[r] = rp_to_fx(m0, scale);
+      }
     }
     __syncthreads();
     // ---- hot stream: every lane walks its run of the panel's rows, sums a row's table entries in a
