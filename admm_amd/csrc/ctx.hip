@@ -1,6 +1,7 @@
 // Context, device vectors, timing and the dim-sized elementwise kernels of the consensus step.
 #include "internal.h"
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 
@@ -59,30 +60,85 @@ int timing_flush(admm_ctx *ctx) {
 
 // ---- reductions ---------------------------------------------------------------------------
 
-// One block sums each scalar's partials in a fixed tree order: deterministic for a given grid.
-__global__ void __launch_bounds__(256) k_finish_partials(const double *partials, int nblocks,
-                                                         double *scalars) {
-  __shared__ double sh[256];
-  const int s = blockIdx.x;
+// Sums up to four rows of partials (rows first .. first + blockDim.x / 256 - 1; a row below `split`
+// holds nblocks_a partials, the others nblocks_b), 256 threads a row, in a fixed tree order:
+// deterministic for a given grid.  The sums go to scalars[] on the device and, with every scalar
+// queued launches left there before, straight into the host's pinned copy; the launch's sequence
+// number follows them, so the host sees the results the moment they exist, without a copy or an
+// interrupt in between.
+__global__ void __launch_bounds__(1024) k_finish_rows(const double *partials, int first, int split, int nblocks_a,
+                                                      int nblocks_b, double *scalars, double *host_scalars,
+                                                      unsigned long long *host_seq, unsigned long long seq) {
+  __shared__ double sh[1024];
+  __shared__ double res[4];
+  const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int row = first + grp;
+  const int nblocks = row < split ? nblocks_a : nblocks_b;
   double acc = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partials[(size_t)s * kMaxPartialBlocks + i];
+  for (int i = t; i < nblocks; i += 256) acc += partials[(size_t)row * kMaxPartialBlocks + i];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    if (t < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) scalars[s] = sh[0];
+  if (t == 0) {
+    scalars[row] = sh[threadIdx.x];
+    res[grp] = sh[threadIdx.x];
+  }
+  __syncthreads();
+  if (threadIdx.x < kPartialScalars) {
+    const int i = threadIdx.x, count = blockDim.x >> 8;
+    const double v = (i >= first && i < first + count) ? res[i - first] : scalars[i];
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_scalars) + i,
+                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int reduce_rows_queue(admm_ctx *ctx, int first, int count, int split, int nblocks_a, int nblocks_b) {
+  if (count <= 0) return ADMM_OK;
+  ADMM_REQUIRE(count <= 4 && first >= 0 && first + count <= kPartialScalars, "reduce_rows_queue: rows %d..%d", first,
+               first + count);
+  hipLaunchKernelGGL(k_finish_rows, dim3(1), dim3(256 * count), 0, ctx->stream, ctx->d_partials, first, split, nblocks_a,
+                     nblocks_b, ctx->d_scalars, ctx->h_scalars_dev, ctx->h_seq_dev, ctx->seq_issued + 1);
+  ADMM_HIP_CHECK(hipGetLastError());
+  ++ctx->seq_issued;
+  return ADMM_OK;
+}
+
+// until ctx->h_scalars holds what the last queued reduction wrote
+int wait_scalars(admm_ctx *ctx) {
+  const unsigned long long want = ctx->seq_issued;
+  volatile unsigned long long *seq = ctx->h_seq;
+  unsigned spins = 0;
+  int idle_seen = 0;
+  while (*seq < want) {
+    if ((++spins & 0x3FFFu) == 0) {  // a fault on the stream must not leave the host spinning
+      const hipError_t e = hipStreamQuery(ctx->stream);
+      if (e != hipSuccess && e != hipErrorNotReady) {
+        set_error("wait_scalars: %s", hipGetErrorString(e));
+        return ADMM_ERR_HIP;
+      }
+      if (e == hipSuccess && *seq < want && ++idle_seen > 4) {
+        set_error("wait_scalars: the stream is idle and reduction %llu has not arrived (at %llu)", want,
+                  (unsigned long long)*seq);
+        return ADMM_ERR_HIP;
+      }
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return ADMM_OK;
 }
 
 int finish_partials(admm_ctx *ctx, int nscalars, int nblocks) {
-  hipLaunchKernelGGL(k_finish_partials, dim3(nscalars), dim3(256), 0, ctx->stream,
-                     ctx->d_partials, nblocks, ctx->d_scalars);
-  ADMM_HIP_CHECK(hipGetLastError());
-  ADMM_HIP_CHECK(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * nscalars,
-                                hipMemcpyDeviceToHost, ctx->stream));
-  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  return ADMM_OK;
+  ADMM_TRY(reduce_rows_queue(ctx, 0, nscalars, nscalars, nblocks, nblocks));
+  return wait_scalars(ctx);
 }
 
 __device__ inline double block_sum_256(double v, double *sh) {
@@ -359,11 +415,23 @@ extern "C" int admm_ctx_create(int device, void *stream, admm_ctx **out) {
   }
   if (hipMalloc(&ctx->d_partials, sizeof(double) * kPartialScalars * kMaxPartialBlocks) != hipSuccess ||
       hipMalloc(&ctx->d_scalars, sizeof(double) * kPartialScalars) != hipSuccess ||
-      hipHostMalloc(&ctx->h_scalars, sizeof(double) * kPartialScalars) != hipSuccess) {
+      hipHostMalloc(&ctx->h_scalars, sizeof(double) * (kPartialScalars + 8), hipHostMallocMapped | hipHostMallocCoherent) !=
+          hipSuccess) {
     set_error("admm_ctx_create: scratch allocation failed");
     admm_ctx_destroy(ctx);
     return ADMM_ERR_NOMEM;
   }
+  // the reductions write their results and a sequence number into this pinned block themselves
+  memset(ctx->h_scalars, 0, sizeof(double) * (kPartialScalars + 8));
+  ctx->h_seq = reinterpret_cast<unsigned long long *>(ctx->h_scalars + kPartialScalars);
+  void *dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, ctx->h_scalars, 0) != hipSuccess) {
+    set_error("admm_ctx_create: the pinned scalars are not mapped into the device");
+    admm_ctx_destroy(ctx);
+    return ADMM_ERR_HIP;
+  }
+  ctx->h_scalars_dev = static_cast<double *>(dev);
+  ctx->h_seq_dev = reinterpret_cast<unsigned long long *>(ctx->h_scalars_dev + kPartialScalars);
   *out = ctx;
   return ADMM_OK;
 }
@@ -403,6 +471,12 @@ extern "C" int admm_timing_enable(admm_ctx *ctx, int on) {
   ADMM_REQUIRE(ctx, "admm_timing_enable: ctx is NULL");
   if (!on) ADMM_TRY(timing_flush(ctx));
   ctx->timing = on != 0;
+  return ADMM_OK;
+}
+
+extern "C" int admm_timing_classes(admm_ctx *ctx, unsigned mask) {
+  ADMM_REQUIRE(ctx, "admm_timing_classes: ctx is NULL");
+  ctx->timing_classes = mask;
   return ADMM_OK;
 }
 

@@ -73,9 +73,13 @@ struct admm_ctx {
   // host mirror for the final few scalars
   double *d_partials = nullptr;
   double *d_scalars = nullptr;  // kPartialScalars doubles (deterministic final sums)
-  double *h_scalars = nullptr;  // pinned
+  double *h_scalars = nullptr;  // pinned, mapped into the device: kPartialScalars doubles, then the sequence number
+  double *h_scalars_dev = nullptr;             // the device's address of h_scalars
+  unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr;
+  unsigned long long seq_issued = 0;            // reductions queued so far
   // timing
   bool timing = false;
+  unsigned timing_classes = ~0u;  // bit k: kernels of class ADMM_K_<k> are timed while `timing` is on
   std::vector<admm_impl::TimingSlot> pending;
   std::vector<admm_impl::TimingSlot> free_slots;
   double k_ms[ADMM_K_COUNT] = {};
@@ -198,7 +202,7 @@ int timing_flush(admm_ctx *ctx);
 struct KernelTimer {
   admm_ctx *ctx;
   int slot;
-  KernelTimer(admm_ctx *c, int kernel) : ctx(c), slot(c->timing ? timing_begin(c, kernel) : -1) {}
+  KernelTimer(admm_ctx *c, int kernel) : ctx(c), slot(c->timing && ((c->timing_classes >> kernel) & 1u) ? timing_begin(c, kernel) : -1) {}
   ~KernelTimer() {
     if (slot >= 0) timing_end(ctx, slot);
   }
@@ -207,6 +211,11 @@ struct KernelTimer {
 // sums `nscalars` rows of `nblocks` partials (row-major [scalar][block]) into ctx->d_scalars in
 // a fixed order, copies them to ctx->h_scalars and synchronises the stream
 int finish_partials(admm_ctx *ctx, int nscalars, int nblocks);
+// queues the sums of partial rows first .. first + count - 1 (count <= 4; rows below `split` hold
+// nblocks_a partials, the others nblocks_b); wait_scalars returns once ctx->h_scalars holds the
+// results of everything queued
+int reduce_rows_queue(admm_ctx *ctx, int first, int count, int split, int nblocks_a, int nblocks_b);
+int wait_scalars(admm_ctx *ctx);
 
 int ensure_rowbuf(admm_csr *csr);
 int build_forward_panels(admm_csr *csr);  // csr.hip

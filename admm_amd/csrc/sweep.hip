@@ -1691,16 +1691,18 @@ static int launch_transposed_impl(admm_csr *csr, bool ftrl_mode, uint64_t p0, ui
 // forward sweep produced (scalars[1]); partials row 2 <- y.(x-z) + rho/2 |x-z|^2.
 // gl_out (optional) keeps the loss part `acc` of the gradient as a float vector; with gl_in the
 // kernel takes that part from such a vector instead of the accumulators (same arithmetic after
-// it, so the result is bit for bit the one of a fresh evaluation at the same x).
+// it, so the result is bit for bit the one of a fresh evaluation at the same x).  With dot_with, partials
+// row 3 <- g . dot_with (same order of additions as k_dot_row on the finished g).
 __global__ void __launch_bounds__(256) k_fg_finish(long long *__restrict__ accum, double inv_scale,
                                                    const float *__restrict__ x,
                                                    const float *__restrict__ z, const float *__restrict__ y,
                                                    float rho, const double *__restrict__ scalars, int add_bias,
                                                    float *__restrict__ g, uint64_t n, double *__restrict__ partials,
-                                                   float *__restrict__ gl_out, const float *__restrict__ gl_in) {
-  __shared__ double sh[4];
+                                                   float *__restrict__ gl_out, const float *__restrict__ gl_in,
+                                                   const float *__restrict__ dot_with) {
+  __shared__ double sh[4], sh2[4];
   const uint64_t stride = (uint64_t)gridDim.x * 256;
-  double reg = 0;
+  double reg = 0, dot = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     float a;
     if (gl_in) {
@@ -1714,42 +1716,35 @@ __global__ void __launch_bounds__(256) k_fg_finish(long long *__restrict__ accum
     }
     const float d = x[i] - (z ? z[i] : 0.0f);
     const float yd = y ? y[i] : 0.0f;
-    g[i] = a + yd + rho * d;
+    const float gi = a + yd + rho * d;
+    g[i] = gi;
     reg += (double)yd * (double)d + 0.5 * (double)rho * (double)d * (double)d;
+    if (dot_with) dot += (double)gi * (double)dot_with[i];
   }
-  for (int off = 32; off > 0; off >>= 1) reg += __shfl_down(reg, off, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = reg;
+  for (int off = 32; off > 0; off >>= 1) {
+    reg += __shfl_down(reg, off, 64);
+    dot += __shfl_down(dot, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x >> 6] = reg;
+    sh2[threadIdx.x >> 6] = dot;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) partials[2 * kMaxPartialBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+  if (threadIdx.x == 0) {
+    partials[2 * kMaxPartialBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (dot_with) partials[3 * kMaxPartialBlocks + blockIdx.x] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+  }
 }
 
-// block b sums partial row first + b
-__global__ void __launch_bounds__(256) k_finish_row(const double *partials, int first, int nblocks, double *scalars) {
-  __shared__ double sh[256];
-  const int row = first + blockIdx.x;
-  double acc = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partials[(size_t)row * kMaxPartialBlocks + i];
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) scalars[row] = sh[0];
+static int reduce_rows2(admm_ctx *ctx, int first, int count, int split, int nblocks_a, int nblocks_b) {
+  return reduce_rows_queue(ctx, first, count, split, nblocks_a, nblocks_b);
 }
 
 static int reduce_rows(admm_ctx *ctx, int first, int count, int nblocks) {
-  if (count <= 0) return ADMM_OK;
-  hipLaunchKernelGGL(k_finish_row, dim3(count), dim3(256), 0, ctx->stream, ctx->d_partials, first, nblocks, ctx->d_scalars);
-  ADMM_HIP_CHECK(hipGetLastError());
-  return ADMM_OK;
+  return reduce_rows_queue(ctx, first, count, first + count, nblocks, nblocks);
 }
 
-static int fetch_scalars(admm_ctx *ctx, int count) {
-  ADMM_HIP_CHECK(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
-  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  return ADMM_OK;
-}
+static int fetch_scalars(admm_ctx *ctx, int) { return wait_scalars(ctx); }
 
 // dot products without a host round trip each: `count` (at most 4) pairs go to partial rows 3.. and
 // d_scalars[3..]; the caller fetches once
@@ -1786,17 +1781,75 @@ static int dots(admm_ctx *ctx, const DotReq *req, int count, uint64_t n, double 
   return ADMM_OK;
 }
 
-// One step of the two-loop recursion with its coefficient computed on the device from the dot
-// product the stream has just reduced (*num): mode 0: alpha = *num / den is stored and y -= alpha x;
-// mode 1: y += (*alpha - *num / den) x.  Same double arithmetic and float rounding as on the host.
+// One step of the two-loop recursion with its coefficient computed on the device.  The dot product
+// it divides arrives as the per-workgroup partials of the launch before (num_parts, nparts of them);
+// every workgroup adds them up in k_finish_row's order.  mode 0: alpha = num / den is stored and
+// y -= alpha x; mode 1: y += (*alpha - num / den) x.  Then y *= post, and when `next` is given the
+// partials of y . next (the product the following step divides) go to next_parts, in k_dot_row's
+// order.  Same double arithmetic and float rounding as separate launches (and as on the host).
 __global__ void __launch_bounds__(256) k_axpy_coef(float *__restrict__ y, const float *__restrict__ x, uint64_t n,
-                                                   const double *__restrict__ num, double den, double *__restrict__ alpha,
-                                                   int mode) {
-  const double q = *num / den;
+                                                   const double *__restrict__ num_parts, int nparts, double den,
+                                                   double *__restrict__ alpha, int mode, float post,
+                                                   const float *__restrict__ next, double *__restrict__ next_parts) {
+  __shared__ double sh[256];
+  double num = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) num += num_parts[i];
+  sh[threadIdx.x] = num;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  const double q = sh[0] / den;
+  __syncthreads();
   const float a = mode == 0 ? (float)(-q) : (float)(*alpha - q);
   const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+  double acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float v = y[i];
+    v += a * x[i];
+    v *= post;
+    y[i] = v;
+    if (next) acc += (double)v * (double)next[i];
+  }
+  if (next) {
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) next_parts[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  }
   if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) *alpha = q;
+}
+
+// The newest correction pair and the four products the solver wants of it, in one pass:
+// s = x - xp, y = g - gp; partial rows 3..6 <- x.x, g.g, y.s, y.y (k_dot_row's order of additions).
+__global__ void __launch_bounds__(256) k_pair(const float *__restrict__ x, const float *__restrict__ xp,
+                                              const float *__restrict__ g, const float *__restrict__ gp,
+                                              float *__restrict__ s, float *__restrict__ y, uint64_t n,
+                                              double *__restrict__ partials) {
+  __shared__ double sh[4][4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  double acc[4] = {0, 0, 0, 0};
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i], gv = g[i];
+    const float sv = xv + -1.0f * xp[i], yv = gv + -1.0f * gp[i];
+    s[i] = sv;
+    y[i] = yv;
+    acc[0] += (double)xv * (double)xv;
+    acc[1] += (double)gv * (double)gv;
+    acc[2] += (double)yv * (double)sv;
+    acc[3] += (double)yv * (double)yv;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    partials[(size_t)(3 + k) * kMaxPartialBlocks + blockIdx.x] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+  }
 }
 
 // number of positions where two vectors (and, when given, two more) differ bit for bit
@@ -1949,21 +2002,23 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
   const float *w[2] = {x, offset};
   int nblk = 0;
   ADMM_TRY(launch_forward(csr, FWD_LBFGS, 0, csr->nrows, w, offset ? 2 : 1, csr->d_rowbuf, &nblk, margins_out));
-  ADMM_TRY(reduce_rows(ctx, 0, 2, nblk));
+  // the bias column's sum (scalar 1) enters the gradient below unless the mask columns carry it
+  const bool bias_scalar = csr->has_bias && !csr->hot_dense;
+  if (bias_scalar) ADMM_TRY(reduce_rows(ctx, 0, 2, nblk));
   ADMM_TRY(launch_transposed(csr, false, 0, csr->npanels));
   const int grid = grid_for(csr->dim, 256, ctx->cu_count * 8);
   {
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
-                       ydual, rho, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, g_out, csr->dim, ctx->d_partials,
-                       gl_out, (const float *)nullptr);
+                       ydual, rho, ctx->d_scalars, bias_scalar ? 1 : 0, g_out, csr->dim, ctx->d_partials,
+                       gl_out, (const float *)nullptr, dot_with);  // g . dot_with rides on the same fetch
     ADMM_HIP_CHECK(hipGetLastError());
   }
-  ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
-  if (dot_with) {  // g . dot_with rides on the same fetch
-    const DotReq rq = {g_out, dot_with};
-    ADMM_TRY(dots_async(ctx, &rq, 1, csr->dim));
-  }
+  // one launch sums the forward sweep's two rows of partials and this kernel's one or two
+  if (bias_scalar)
+    ADMM_TRY(reduce_rows(ctx, 2, dot_with ? 2 : 1, grid));
+  else
+    ADMM_TRY(reduce_rows2(ctx, 0, dot_with ? 4 : 3, 2, nblk, grid));
   if (f_out) {
     ADMM_TRY(fetch_scalars(ctx, dot_with ? 4 : 3));
     *f_out = ctx->h_scalars[0] + ctx->h_scalars[2];
@@ -2213,10 +2268,12 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     if (!csr->d_dmargin) ADMM_HIP_CHECK(hipMalloc(&csr->d_dmargin, sizeof(float) * csr->nrows));
   }
   float *g = ctx->lbfgs_ws, *xp = g + dim, *gp = xp + dim, *d = gp + dim;
-  float *s_new = d + dim, *y_new = s_new + dim;  // the newest pair, before it is known to be usable
-  float *S = y_new + dim, *Y = S + (uint64_t)P.m * dim;
-  std::vector<double> ys_hist(P.m, 0.0);
-  int head = 0, count = 0;  // ring: newest at (head-1) mod m
+  // rings of m+1 slots: the pairs in use are the `count` slots before `head`, and slot `head` takes
+  // the newest pair before it is known to be usable (so it never overwrites one still in use)
+  const int slots = P.m + 1;
+  float *S = d + dim, *Y = S + (uint64_t)slots * dim;
+  std::vector<double> ys_hist(slots, 0.0);
+  int head = 0, count = 0;  // newest pair in use at (head-1) mod slots
 
   for (float **p : {&csr->d_cache_x, &csr->d_cache_off, &csr->d_cache_gl})
     if (!*p) ADMM_HIP_CHECK(hipMalloc(p, sizeof(float) * dim));
@@ -2273,7 +2330,8 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   if (from_cache) {
     const int grid = grid_for(dim, 256, ctx->cu_count * 8);
     hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, (long long *)nullptr, 0.0, x, z, ydual, rho,
-                       ctx->d_scalars, 0, g, dim, ctx->d_partials, (float *)nullptr, (const float *)csr->d_cache_gl);
+                       ctx->d_scalars, 0, g, dim, ctx->d_partials, (float *)nullptr, (const float *)csr->d_cache_gl,
+                       (const float *)nullptr);
     ADMM_HIP_CHECK(hipGetLastError());
     ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
     ADMM_TRY(fetch_scalars(ctx, 3));
@@ -2318,7 +2376,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
       hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
                          ydual, rho, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, g, dim, ctx->d_partials,
-                         csr->d_cache_gl, (const float *)nullptr);
+                         csr->d_cache_gl, (const float *)nullptr, (const float *)nullptr);
       ADMM_HIP_CHECK(hipGetLastError());
     }
     ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
@@ -2360,12 +2418,19 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) <= P.epsilon) return done();
   ADMM_TRY(vec_lincomb(ctx, d, g, -2.0f, g, dim));  // d = g - 2g = -g
   double step = 1.0 / std::sqrt(gg);
+  int dg_row = -1;  // scalar slot holding g . d for the next line search, when the device has it
   for (int it = 0; it < P.max_iter; ++it) {
     ADMM_TRY(admm_vec_copy(ctx, xp, x, dim));
     ADMM_TRY(admm_vec_copy(ctx, gp, g, dim));
     const double fp = f, lossp = loss;
     double dginit = 0;
-    ADMM_TRY(vec_dot(ctx, g, d, dim, &dginit));
+    if (dg_row >= 0) {  // the two-loop recursion's last step left g . d on the device
+      ADMM_TRY(fetch_scalars(ctx, dg_row + 1));
+      dginit = ctx->h_scalars[dg_row];
+      dg_row = -1;
+    } else {
+      ADMM_TRY(vec_dot(ctx, g, d, dim, &dginit));
+    }
     if (dginit > 0) break;
     const double dgtest = P.ftol * dginit;
     // Along x + s d the margins are m0 + s X d and the rest of the objective (the dual term and the
@@ -2440,48 +2505,49 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       break;
     }
     ++iters;
-    ADMM_TRY(vec_sub(ctx, s_new, x, xp, dim));
-    ADMM_TRY(vec_sub(ctx, y_new, g, gp, dim));
+    if (it + 1 >= P.max_iter) break;  // nothing below serves the last iteration
+    float *s_new = S + (uint64_t)head * dim, *y_new = Y + (uint64_t)head * dim;
+    const int egrid = grid_for(dim, 256, ctx->cu_count * 8);
     double ys = 0, yy = 0;
     {
-      const DotReq rq[4] = {{x, x}, {g, g}, {y_new, s_new}, {y_new, y_new}};
-      double out[4];
-      ADMM_TRY(dots(ctx, rq, 4, dim, out));
-      xx = out[0];
-      gg = out[1];
-      ys = out[2];
-      yy = out[3];
+      hipLaunchKernelGGL(k_pair, dim3(egrid), dim3(256), 0, ctx->stream, x, xp, g, gp, s_new, y_new, dim, ctx->d_partials);
+      ADMM_HIP_CHECK(hipGetLastError());
+      ADMM_TRY(reduce_rows(ctx, 3, 4, egrid));
+      ADMM_TRY(fetch_scalars(ctx, 7));
+      xx = ctx->h_scalars[3];
+      gg = ctx->h_scalars[4];
+      ys = ctx->h_scalars[5];
+      yy = ctx->h_scalars[6];
     }
     if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) <= P.epsilon) break;
-    if (ys > 1e-30) {
-      // only a pair with positive curvature enters the ring (a rejected one must not overwrite the
-      // oldest pair that is still in use)
-      ADMM_TRY(admm_vec_copy(ctx, S + (uint64_t)head * dim, s_new, dim));
-      ADMM_TRY(admm_vec_copy(ctx, Y + (uint64_t)head * dim, y_new, dim));
+    if (ys > 1e-30) {  // only a pair with positive curvature enters the ring
       ys_hist[head] = ys;
-      head = (head + 1) % P.m;
+      head = (head + 1) % slots;
       if (count < P.m) ++count;
     }
-    // two-loop recursion; its coefficients stay on the device (no host round trip inside)
+    // two-loop recursion; its coefficients stay on the device (no host round trip inside), and every
+    // step also forms the product the next one divides
     ADMM_TRY(vec_lincomb(ctx, d, g, -2.0f, g, dim));  // d = -g
-    const int egrid = grid_for(dim, 256, ctx->cu_count * 8);
-    double *tmp = ctx->d_scalars + 3;  // where dots_async leaves its first product
-    for (int i = 0; i < count; ++i) {  // newest -> oldest
-      const int idx = (head - 1 - i + 2 * P.m) % P.m;
-      const DotReq rq = {S + (uint64_t)idx * dim, d};
-      ADMM_TRY(dots_async(ctx, &rq, 1, dim));
-      hipLaunchKernelGGL(k_axpy_coef, dim3(egrid), dim3(256), 0, ctx->stream, d, Y + (uint64_t)idx * dim, dim, tmp,
-                         ys_hist[idx], ctx->d_lb + i, 0);
+    if (count > 0) {
+      const int total = 2 * count;
+      auto slot = [&](int i) { return (uint64_t)((head - 1 - i + 2 * slots) % slots); };  // i = 0: newest
+      // step j < count: pair j, newest -> oldest; then oldest -> newest
+      auto pair_of = [&](int j) { return j < count ? j : total - 1 - j; };
+      auto dot_vec = [&](int j) { return (j < count ? S : Y) + slot(pair_of(j)) * dim; };
+      auto part_row = [&](int j) { return ctx->d_partials + (size_t)(3 + (j & 1)) * kMaxPartialBlocks; };
+      hipLaunchKernelGGL(k_dot_row, dim3(egrid), dim3(256), 0, ctx->stream, dot_vec(0), d, dim, part_row(0));
       ADMM_HIP_CHECK(hipGetLastError());
-    }
-    if (ys > 1e-30) ADMM_TRY(vec_scale(ctx, d, (float)(ys / yy), dim));
-    for (int i = count - 1; i >= 0; --i) {  // oldest -> newest
-      const int idx = (head - 1 - i + 2 * P.m) % P.m;
-      const DotReq rq = {Y + (uint64_t)idx * dim, d};
-      ADMM_TRY(dots_async(ctx, &rq, 1, dim));
-      hipLaunchKernelGGL(k_axpy_coef, dim3(egrid), dim3(256), 0, ctx->stream, d, S + (uint64_t)idx * dim, dim, tmp,
-                         ys_hist[idx], ctx->d_lb + i, 1);
-      ADMM_HIP_CHECK(hipGetLastError());
+      for (int j = 0; j < total; ++j) {
+        const int i = pair_of(j);
+        const float post = (j == count - 1 && ys > 1e-30) ? (float)(ys / yy) : 1.0f;  // the initial Hessian's scale
+        const float *next = j + 1 < total ? dot_vec(j + 1) : g;  // last: g . d for the line search
+        hipLaunchKernelGGL(k_axpy_coef, dim3(egrid), dim3(256), 0, ctx->stream, d, (j < count ? Y : S) + slot(i) * dim, dim,
+                           part_row(j), egrid, ys_hist[slot(i)], ctx->d_lb + i, j < count ? 0 : 1, post, next,
+                           part_row(j + 1));
+        ADMM_HIP_CHECK(hipGetLastError());
+      }
+      dg_row = 3 + (total & 1);
+      ADMM_TRY(reduce_rows(ctx, dg_row, 1, egrid));
     }
     step = 1.0;
   }

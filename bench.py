@@ -406,7 +406,9 @@ def run_admm(args):
     for _ in range(args.warmup):
         step()
     job.barrier()
-    ctx.timing_enable(True)
+    # only the two sweeps are timed: an event pair around each of the step's small kernels as well would
+    # stretch the step it measures
+    ctx.timing_enable(True, classes=[capi.K_FORWARD, capi.K_TRANSPOSED])
     ctx.timing_reset()
     evals = fwd_sweeps = tr_sweeps = 0
     t0 = time.perf_counter()

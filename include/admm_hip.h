@@ -56,6 +56,9 @@ int admm_sync(admm_ctx *ctx);
 #define ADMM_K_FORWARD_EVAL 4 /* the same sweep in its prediction / logloss form */
 #define ADMM_K_COUNT 5
 int admm_timing_enable(admm_ctx *ctx, int on);
+/* restricts the timing to the classes whose bit (1u << ADMM_K_*) is set; all classes by default.  Every
+ * timed launch costs two event records on the stream, which a step of many small kernels feels. */
+int admm_timing_classes(admm_ctx *ctx, unsigned mask);
 int admm_timing_reset(admm_ctx *ctx);
 int admm_timing_get(admm_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 
