@@ -1255,7 +1255,7 @@ struct TArgs {
   float scale;
   uint32_t nblocks, col_block;
   uint64_t panel0, npanels;  // panels [panel0, panel0 + npanels) are swept by this launch
-  int no_gather;             // calibration runs only: skip the per-row gathers (results are then meaningless)
+  int no_gather;             // calibration runs only: bit 0 skips the per-row gathers, bit 1 the global adds (results are then meaningless)
   // FTRL form over one panel (= one mini-batch): fz != nullptr applies the batch's update to the
   // cell's columns right here (the cell holds every entry the batch stores in them) instead of adding
   // the sums to g1 / g2 for a separate pass
@@ -1361,7 +1361,7 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
         vb = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.tval + k2));
       }
       float xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
-      if (a.no_gather) {
+      if (a.no_gather & 1) {
         xa0 = __uint_as_float(ra.x), xa1 = __uint_as_float(ra.y), xa2 = __uint_as_float(ra.z), xa3 = __uint_as_float(ra.w);
         xb0 = __uint_as_float(rb.x), xb1 = __uint_as_float(rb.y), xb2 = __uint_as_float(rb.z), xb3 = __uint_as_float(rb.w);
       } else {
@@ -1451,6 +1451,7 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
     }
     return;
   }
+  if (a.no_gather & 2) return;
   for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
     const fx_t s = acc[c];
     if (FTRL) {
@@ -1647,7 +1648,7 @@ static int launch_transposed_impl(admm_csr *csr, bool ftrl_mode, uint64_t p0, ui
   a.col_block = csr->col_block;
   // measurement aid: a gather-free run moves a known number of bytes, which calibrates the
   // hardware counters; it computes nothing useful
-  a.no_gather = getenv("ADMM_CALIBRATE_NO_GATHER") != nullptr;
+  a.no_gather = (getenv("ADMM_CALIBRATE_NO_GATHER") != nullptr ? 1 : 0) | (getenv("ADMM_CALIBRATE_NO_FLUSH") != nullptr ? 2 : 0);
   const size_t lds = sizeof(fx_t) * csr->col_block * (ftrl_mode ? 2 : 1);
   // more than half of the CU's LDS: one workgroup per CU, so give it the full 1024 threads
   const bool big = lds > 72 * 1024;
