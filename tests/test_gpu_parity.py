@@ -364,6 +364,48 @@ def test_logistic_fg(ctx, oracle, binary, mean, panel):
     dev.destroy()
 
 
+def test_lbfgs_short_memory_follows_the_oracle(ctx, oracle):
+    """two correction pairs only: the ring of pairs wraps every other iteration, and the newest pair is
+    written before it is known to be usable (it must not land on a pair still in use)"""
+    dim = 90
+    raw = make_synth_csr(1200, dim, 9, seed=47)
+    tr = oracle.translate(raw)
+    z = np.zeros(dim, np.float32)
+
+    def fg(xx):
+        return oracle.logistic_fg(tr, dim, xx, None, z, None, 0.5)
+
+    dev = upload(ctx, raw, dim).build_transposed(col_block=64)
+    for m, iters in ((1, 6), (2, 7), (3, 9)):
+        x_ref, f_ref, ev_ref, it_ref = oracle.lbfgs_solve(np.zeros(dim, np.float32), fg, m=m, max_iter=iters)
+        x = ctx.vec(dim)
+        res = dev.lbfgs_solve(x, z=ctx.vec(dim), rho=0.5, m=m, max_iter=iters, linesearch=1)
+        assert (res["evals"], res["iters"]) == (ev_ref, it_ref)
+        close(res["f"], f_ref)
+        close(x.download(), x_ref, rtol=1e-4, atol=1e-6)
+    dev.destroy()
+
+
+def test_timing_can_be_restricted_to_kernel_classes(ctx):
+    from admm_amd import capi
+    dim = 300
+    raw = make_synth_csr(3000, dim, 12, seed=5)
+    dev = upload(ctx, raw, dim).build_transposed(col_block=64)
+    x, g = ctx.vec(dim), ctx.vec(dim)
+    ctx.timing_enable(True, classes=[capi.K_FORWARD, capi.K_TRANSPOSED])
+    ctx.timing_reset()
+    f1 = dev.logistic_fg(x, g, rho=0.1)
+    assert ctx.timing_get(capi.K_FORWARD)[1] == 1 and ctx.timing_get(capi.K_TRANSPOSED)[1] == 1
+    assert ctx.timing_get(capi.K_ELEMENTWISE)[1] == 0
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    f2 = dev.logistic_fg(x, g, rho=0.1)
+    assert ctx.timing_get(capi.K_ELEMENTWISE)[1] >= 1
+    ctx.timing_enable(False)
+    assert f1 == f2
+    dev.destroy()
+
+
 @pytest.mark.parametrize("linesearch", [0, 1, 2])
 def test_lbfgs_solve(ctx, oracle, linesearch):
     """linesearch 0 evaluates trial points from the margins, 1 by full sweeps: same trajectory"""
