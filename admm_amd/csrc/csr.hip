@@ -1289,6 +1289,10 @@ int ensure_rowbuf(admm_csr *csr) {
 }
 
 int ensure_taccum(admm_csr *csr) {
+  if (!csr->d_gs) {
+    ADMM_HIP_CHECK(hipMalloc(&csr->d_gs, sizeof(long long) * kFpHot));
+    ADMM_HIP_CHECK(hipMemsetAsync(csr->d_gs, 0, sizeof(long long) * kFpHot, csr->ctx->stream));
+  }
   if (csr->d_g1) return ADMM_OK;
   const uint64_t padded = (uint64_t)csr->nblocks * csr->col_block;
   ADMM_HIP_CHECK(hipMalloc(&csr->d_g1, sizeof(long long) * padded));
@@ -1315,7 +1319,7 @@ static void free_csr(admm_csr *c) {
                   c->d_trow,   c->d_tcol, c->d_tval, c->d_g1,    c->d_g2,
                   c->d_wsum,   c->d_perm, c->d_inv,  c->d_hmask, c->d_hwarm, c->d_crowptr, c->d_ccol, c->d_cval, c->d_dep, c->d_seqcol,
                   c->d_fcol,   c->d_frow, c->d_fval, c->d_fptr, c->d_hcol, c->d_hval, c->d_hbase, c->d_hfirst,
-                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst, c->d_hmaskT, c->d_mpart};
+                  c->d_tcw,    c->d_tcv,  c->d_tcbase, c->d_tcfirst, c->d_hmaskT, c->d_mpart, c->d_gs};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete c;

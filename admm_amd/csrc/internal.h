@@ -187,6 +187,10 @@ struct admm_csr {
   // per-coordinate accumulators of the transposed sweep: 64-bit fixed point (value * 2^fx_shift),
   // so that sums are exact integer adds (order-independent, reproducible)
   long long *d_g1 = nullptr, *d_g2 = nullptr;
+  // X^T r of the first kFpHot STORED ids (row masks' columns and the column stream's), by stored id: those
+  // sums come from every workgroup of their kernels, and adds to adjacent words share a memory request
+  // where adds to their scattered caller's ids take one each; k_fg_finish picks them up and clears them
+  long long *d_gs = nullptr;
   long long *d_mpart = nullptr;  // mini-batch FTRL: the mask columns' two sums, spread over a few copies by the forward sweep
   int fx_shift = 40;
   float vmax = 1.0f;  // max |val| of the set

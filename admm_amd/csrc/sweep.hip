@@ -661,6 +661,7 @@ struct RpArgs {
   double *partials;
   unsigned long long *g1;  // X^T r of the mask columns goes here (fixed point, gscale), nullptr: not wanted
   unsigned long long *g2;  // FTRL form: the sums of the squared gradients of those columns
+  unsigned long long *gs;  // when given (not in the FTRL form): the mask columns' sums go to gs[stored id] instead of g1[perm[..]]
   unsigned long long *mpart;  // FTRL form: [kMaskSlots][2][kMaskCols] sums by workgroup index mod kMaskSlots, instead of adds to g1 / g2
   float gscale;
   uint64_t panel0, pcount; // panels [panel0, panel0 + pcount) are swept by this launch
@@ -987,6 +988,8 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         if (wacc[tid]) atomicAdd(slot + tid, wacc[tid]);
         if (wacc2[tid]) atomicAdd(slot + kMaskCols + tid, wacc2[tid]);
       }
+    } else if (MODE != FWD_FTRL && a.gs) {
+      if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.gs + tid, wacc[tid]);
     } else {
       if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.g1 + a.perm[tid], wacc[tid]);
       if (MODE == FWD_FTRL && tid < (int)kMaskCols && wacc2[tid]) atomicAdd(a.g2 + a.perm[tid], wacc2[tid]);
@@ -1112,6 +1115,7 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, uint64_t r0, uint6
       a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
       a.g2 = reinterpret_cast<unsigned long long *>(csr->d_g2);
       if (mode == FWD_FTRL) a.mpart = reinterpret_cast<unsigned long long *>(csr->d_mpart);
+      else a.gs = reinterpret_cast<unsigned long long *>(csr->d_gs);
     }
   }
   a.panel0 = r0 / csr->fp_rows;
@@ -1482,6 +1486,7 @@ struct TcArgs {
   uint32_t ncols;
   const uint32_t *perm;  // stored id -> index in g1 (nullptr: identity)
   unsigned long long *g1;
+  unsigned long long *gs;  // when given: the sums go to gs[stored id] (adjacent words) instead of g1[perm[..]]
   float scale;
 };
 
@@ -1585,7 +1590,7 @@ __global__ void __launch_bounds__(kTcLanes) k_transposed_cs(TcArgs a) {
   for (uint32_t j = tid; j < a.ncols; j += kTcLanes) {
     const uint32_t c = j + rot < a.ncols ? j + rot : j + rot - a.ncols;
     const fx_t v = cs_acc[c];
-    if (v != 0) atomicAdd(&a.g1[a.perm ? a.perm[c] : c], v);
+    if (v != 0) atomicAdd(a.gs ? &a.gs[c] : &a.g1[a.perm ? a.perm[c] : c], v);
   }
 }
 
@@ -1601,6 +1606,7 @@ static int launch_column_stream(admm_csr *csr) {
   a.ncols = csr->tc_cols;
   a.perm = csr->d_perm;
   a.g1 = reinterpret_cast<unsigned long long *>(csr->d_g1);
+  a.gs = reinterpret_cast<unsigned long long *>(csr->d_gs);
   a.scale = std::ldexp(1.0f, csr->fx_shift);
   const size_t lds = sizeof(fx_t) * csr->tc_cols + sizeof(float) * 2 * (kTcRows + 1);
   static bool raised[64] = {};
@@ -1688,7 +1694,8 @@ static int launch_transposed_impl(admm_csr *csr, bool ftrl_mode, uint64_t p0, ui
 // f, g assembly
 // ---------------------------------------------------------------------------------------------
 
-// g = acc + y + rho (x - z), acc reset to 0; column 0 also receives the bias-column sum the
+// g = acc + y + rho (x - z), acc reset to 0 (acc: the column's word of `accum`, plus its word of `gs` when its
+// stored id has one); column 0 also receives the bias-column sum the
 // forward sweep produced (scalars[1]); partials row 2 <- y.(x-z) + rho/2 |x-z|^2.
 // gl_out (optional) keeps the loss part `acc` of the gradient as a float vector; with gl_in the
 // kernel takes that part from such a vector instead of the accumulators (same arithmetic after
@@ -1700,7 +1707,8 @@ __global__ void __launch_bounds__(256) k_fg_finish(long long *__restrict__ accum
                                                    float rho, const double *__restrict__ scalars, int add_bias,
                                                    float *__restrict__ g, uint64_t n, double *__restrict__ partials,
                                                    float *__restrict__ gl_out, const float *__restrict__ gl_in,
-                                                   const float *__restrict__ dot_with) {
+                                                   const float *__restrict__ dot_with,
+                                                   const uint32_t *__restrict__ inv, long long *__restrict__ gs) {
   __shared__ double sh[4], sh2[4];
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   double reg = 0, dot = 0;
@@ -1709,8 +1717,16 @@ __global__ void __launch_bounds__(256) k_fg_finish(long long *__restrict__ accum
     if (gl_in) {
       a = gl_in[i];
     } else {
-      double ad = (double)accum[i] * inv_scale;
+      long long q = accum[i];
       accum[i] = 0;
+      if (gs) {  // the sums kept by stored id (inv: caller's id -> stored id, nullptr: identity)
+        const uint32_t sid = inv ? inv[i] : (uint32_t)i;
+        if (sid < kFpHot) {
+          q += gs[sid];
+          gs[sid] = 0;
+        }
+      }
+      double ad = (double)q * inv_scale;
       if (add_bias && i == 0) ad += scalars[1];
       a = (float)ad;
       if (gl_out) gl_out[i] = a;
@@ -2012,7 +2028,7 @@ static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
                        ydual, rho, ctx->d_scalars, bias_scalar ? 1 : 0, g_out, csr->dim, ctx->d_partials,
-                       gl_out, (const float *)nullptr, dot_with);  // g . dot_with rides on the same fetch
+                       gl_out, (const float *)nullptr, dot_with, csr->d_inv, csr->d_gs);  // g . dot_with rides on the same fetch
     ADMM_HIP_CHECK(hipGetLastError());
   }
   // one launch sums the forward sweep's two rows of partials and this kernel's one or two
@@ -2332,7 +2348,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
     const int grid = grid_for(dim, 256, ctx->cu_count * 8);
     hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, (long long *)nullptr, 0.0, x, z, ydual, rho,
                        ctx->d_scalars, 0, g, dim, ctx->d_partials, (float *)nullptr, (const float *)csr->d_cache_gl,
-                       (const float *)nullptr);
+                       (const float *)nullptr, (const uint32_t *)nullptr, (long long *)nullptr);
     ADMM_HIP_CHECK(hipGetLastError());
     ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
     ADMM_TRY(fetch_scalars(ctx, 3));
@@ -2377,7 +2393,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
       hipLaunchKernelGGL(k_fg_finish, dim3(grid), dim3(256), 0, ctx->stream, csr->d_g1, std::ldexp(1.0, -csr->fx_shift), x, z,
                          ydual, rho, ctx->d_scalars, (csr->has_bias && !csr->hot_dense) ? 1 : 0, g, dim, ctx->d_partials,
-                         csr->d_cache_gl, (const float *)nullptr, (const float *)nullptr);
+                         csr->d_cache_gl, (const float *)nullptr, (const float *)nullptr, csr->d_inv, csr->d_gs);
       ADMM_HIP_CHECK(hipGetLastError());
     }
     ADMM_TRY(reduce_rows(ctx, 2, 1, grid));
