@@ -2006,7 +2006,7 @@ __global__ void __launch_bounds__(256) k_mask_colsums(const unsigned long long *
   static_assert(kWarmWords == 3, "the walk above names three words");
   if (h) atomicAdd(&acc[lane], h);
   __syncthreads();
-  if (acc[tid]) atomicAdd(g1 + perm[tid], acc[tid]);
+  if (acc[tid]) atomicAdd(g1 + (perm ? perm[tid] : (uint32_t)tid), acc[tid]);
 }
 
 static int logistic_fg(admm_csr *csr, const float *x, const float *offset, const float *z, const float *ydual,
@@ -2382,8 +2382,8 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       hipLaunchKernelGGL(k_mask_colsums, dim3(mgrid), dim3(256), 0, ctx->stream,
                          reinterpret_cast<const unsigned long long *>(csr->d_hmask),
                          reinterpret_cast<const unsigned long long *>(csr->d_hwarm), csr->d_rowbuf,
-                         csr->nrows, std::ldexp(1.0f, csr->fx_shift), csr->d_perm,
-                         reinterpret_cast<unsigned long long *>(csr->d_g1));
+                         csr->nrows, std::ldexp(1.0f, csr->fx_shift), (const uint32_t *)nullptr,
+                         reinterpret_cast<unsigned long long *>(csr->d_gs));  // by stored id, as the forward sweep leaves them
       ADMM_HIP_CHECK(hipGetLastError());
     }
     ADMM_TRY(launch_transposed(csr, false, 0, csr->npanels));
