@@ -673,8 +673,11 @@ __device__ inline unsigned long long rp_d2fx(double s) {
   return (unsigned long long)(__double_as_longlong(s + 6755399441055744.0) - 0x4338000000000000ll);
 }
 
+#ifndef ADMM_RP_PRELIST
+#define ADMM_RP_PRELIST (MODE == FWD_FTRL)
+#endif
 template <int MODE, bool HASVAL>
-__global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
+__global__ void __launch_bounds__(kRpThreads, MODE == FWD_FTRL ? 2 : 4) k_forward_rp(RpArgs a) {
   extern __shared__ unsigned long long rp_acc[];                     // [panel_rows] margins, fixed point; then float hot[nhot + 1]
   // leading entries of w: as they are (sets with values) or times 2^shift with the fraction dropped
   // (pattern sets: an entry's addend is then the table entry itself); hot[nhot] = 0 for filler words
@@ -683,11 +686,32 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   __shared__ float tab[8 * 256];                                     // byte of the first mask word -> sum of its weights
   __shared__ unsigned long long wacc[kMaskCols];                     // X^T r of the mask columns, this workgroup
   __shared__ unsigned long long wacc2[MODE == FWD_FTRL ? kMaskCols : 1];  // FTRL form: squared-gradient sums of those columns
-  __shared__ double shred[kRpThreads / 64];
+  __shared__ double shred[kRpThreads / 64], shred1[kRpThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool dense = a.hmask != nullptr;
   const bool colsums = dense && (MODE == FWD_LBFGS || MODE == FWD_FTRL) && a.g1 != nullptr;
   const uint32_t R = a.panel_rows;
+  // What the workgroup's first panel starts with is asked for before anything else (its pointers, the row
+  // each lane's run starts in, the masks of each lane's first row): a launch of short panels, one per
+  // workgroup, is otherwise a chain of dependent loads, one memory latency per phase.  Barriers wait for
+  // LDS only, so these loads stay in flight through the set-up below.
+  const uint64_t p_first = a.panel0 + blockIdx.x;
+  uint64_t pre_hb0 = 0, pre_hb1 = 0, pre_f0 = 0, pre_f1 = 0;
+  uint32_t pre_row = 0;
+  unsigned long long pre_m = 0, pre_w[kWarmWords] = {};
+  if (p_first < a.panel0 + a.pcount) {
+    pre_hb0 = a.hbase[p_first];
+    pre_hb1 = a.hbase[p_first + 1];
+    pre_f0 = a.fptr[p_first];
+    pre_f1 = a.fptr[p_first + 1];
+    pre_row = a.hfirst[p_first * kRpThreads + tid];
+    const uint64_t r = p_first * R + tid;
+    if (MODE == FWD_FTRL && dense && (uint32_t)tid < R && r < a.nrows) {
+      pre_m = a.hmask[r];
+#pragma unroll
+      for (int w = 0; w < kWarmWords; ++w) pre_w[w] = a.hwarm[r * kWarmWords + w];
+    }
+  }
   // the fixed-point shift of this sweep: the largest s with (longest row) * max |w v| * 2^s < 2^50, at
   // most 40 -- a margin, and every partial sum of one, then is an integer below 2^51 in magnitude,
   // which a double holds exactly.  Every workgroup derives it from the same maxima.
@@ -722,7 +746,10 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
     raw[tid] = dense ? a.w[tid] : 0.0f;  // a set with masks has at least kMaskCols columns
   }
   __syncthreads();
-  if (dense) {
+  // (short panels: building the byte table would cost more than the lookups it saves; their rows walk the
+  // first word's bits instead, byte by byte, which adds the same floats in the same order)
+  const bool use_tab = dense && R > 512;
+  if (use_tab) {
     for (int i = tid; i < 8 * 256; i += kRpThreads) {
       const int g = i >> 8, byte = i & 255;
       float t = 0.0f;
@@ -735,6 +762,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
   const float w0 = a.add_bias ? a.w[0] : 0.0f;
   double acc0 = 0, acc1 = 0;
   i32x4 cacc[4] = {};  // column sums of the first mask word, by digit (see the epilogue)
+  bool did_tile = false;  // this wave has put rows into cacc
   __syncthreads();
   for (uint64_t p = a.panel0 + blockIdx.x; p < a.panel0 + a.pcount; p += gridDim.x) {
     const uint64_t r0 = p * R;
@@ -749,9 +777,15 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         for (int j = 0; j < 4; ++j) {
           const uint32_t r = rb4 + j * kRpThreads;
           if (r < nr) {
-            mm[j] = a.hmask[r0 + r];
+            if (MODE == FWD_FTRL && j == 0 && p == p_first && rb4 == (uint32_t)tid) {
+              mm[0] = pre_m;
 #pragma unroll
-            for (int w = 0; w < kWarmWords; ++w) ww[j][w] = a.hwarm[(r0 + r) * kWarmWords + w];
+              for (int w = 0; w < kWarmWords; ++w) ww[0][w] = pre_w[w];
+            } else {
+              mm[j] = a.hmask[r0 + r];
+#pragma unroll
+              for (int w = 0; w < kWarmWords; ++w) ww[j][w] = a.hwarm[(r0 + r) * kWarmWords + w];
+            }
           }
         }
       }
@@ -761,9 +795,25 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         if (r >= nr) break;
         float m0 = w0;
         if (dense) {
-          const unsigned long long m = mm[j];
+          unsigned long long m = mm[j];
+          if (use_tab) {
 #pragma unroll
-          for (int g = 0; g < 8; ++g) m0 += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
+            for (int g = 0; g < 8; ++g) m0 += tab[g * 256 + (int)((m >> (8 * g)) & 255)];
+          } else {
+            float t = 0.0f;
+            int cur = 0;
+            while (m) {
+              const int b = __builtin_ctzll(m);
+              if ((b >> 3) != cur) {
+                m0 += t;
+                t = 0.0f;
+                cur = b >> 3;
+              }
+              t += raw[b];
+              m &= m - 1;
+            }
+            m0 += t;
+          }
 #pragma unroll
           for (int w = 0; w < kWarmWords; ++w) {
             unsigned long long mw = ww[j][w];
@@ -777,13 +827,25 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
       }
     }
     __syncthreads();
+    // the first four list entries of each lane are asked for now: they arrive while the hot stream is walked
+    const bool first = p == p_first;
+    const uint64_t beg = first ? pre_f0 : a.fptr[p], end = first ? pre_f1 : a.fptr[p + 1];
+    uint32_t pc[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+    const bool pre_list = ADMM_RP_PRELIST && beg + tid + 3 * kRpThreads < end;
+    if (pre_list) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pc[j] = __builtin_nontemporal_load(a.fcol + beg + tid + j * kRpThreads);
+        pq[j] = __builtin_nontemporal_load(a.frow + beg + tid + j * kRpThreads);
+      }
+    }
     // ---- hot stream: every lane walks its run of the panel's rows, sums a row's table entries in a
     // register (exact: integer-valued doubles below 2^51) and adds the sum to the row's margin when
     // the row ends; a run that ends inside a row leaves its part at the end
     {
-      const uint64_t hb = a.hbase[p];
-      const uint32_t nq = (uint32_t)((a.hbase[p + 1] - hb) / (4 * kRpThreads));  // groups of four words per lane
-      uint32_t row = a.hfirst[p * kRpThreads + tid];
+      const uint64_t hb = first ? pre_hb0 : a.hbase[p];
+      const uint32_t nq = (uint32_t)(((first ? pre_hb1 : a.hbase[p + 1]) - hb) / (4 * kRpThreads));  // groups of four words per lane
+      uint32_t row = first ? pre_row : a.hfirst[p * kRpThreads + tid];
       const u32x2 *src = reinterpret_cast<const u32x2 *>(a.hcol + hb) + tid;
       const f32x4 *vsrc = HASVAL ? reinterpret_cast<const f32x4 *>(a.hval + hb) + tid : nullptr;
       double sum = 0.0;
@@ -842,15 +904,20 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
     // ---- the other entries: stream, gather, add.  They come in the order of their column ids, so
     // adjacent lanes gather from the same or neighbouring cache lines.
     {
-      const uint64_t beg = a.fptr[p], end = a.fptr[p + 1];
       uint64_t k = beg + tid;
       for (; k + 3 * kRpThreads < end; k += 4 * kRpThreads) {
-        const uint32_t c0 = __builtin_nontemporal_load(a.fcol + k), c1 = __builtin_nontemporal_load(a.fcol + k + kRpThreads),
-                       c2 = __builtin_nontemporal_load(a.fcol + k + 2 * kRpThreads),
-                       c3 = __builtin_nontemporal_load(a.fcol + k + 3 * kRpThreads);
-        const uint32_t q0 = __builtin_nontemporal_load(a.frow + k), q1 = __builtin_nontemporal_load(a.frow + k + kRpThreads),
-                       q2 = __builtin_nontemporal_load(a.frow + k + 2 * kRpThreads),
-                       q3 = __builtin_nontemporal_load(a.frow + k + 3 * kRpThreads);
+        uint32_t c0, c1, c2, c3, q0, q1, q2, q3;
+        if (pre_list && k == beg + tid) {
+          c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3];
+          q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3];
+        } else {
+          c0 = __builtin_nontemporal_load(a.fcol + k), c1 = __builtin_nontemporal_load(a.fcol + k + kRpThreads);
+          c2 = __builtin_nontemporal_load(a.fcol + k + 2 * kRpThreads);
+          c3 = __builtin_nontemporal_load(a.fcol + k + 3 * kRpThreads);
+          q0 = __builtin_nontemporal_load(a.frow + k), q1 = __builtin_nontemporal_load(a.frow + k + kRpThreads);
+          q2 = __builtin_nontemporal_load(a.frow + k + 2 * kRpThreads);
+          q3 = __builtin_nontemporal_load(a.frow + k + 3 * kRpThreads);
+        }
         float x0 = a.w[c0], x1 = a.w[c1], x2 = a.w[c2], x3 = a.w[c3];
         if (HASVAL) {
           x0 *= __builtin_nontemporal_load(a.fval + k);
@@ -906,6 +973,7 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
         }
       }
       if (colsums) {
+        did_tile = true;
         // X^T r of the mask columns over these 64 rows.  First word (64 columns, about half of a row's
         // entries): a 64 x 64 bit matrix times the residuals on the matrix unit.  The residuals, offset
         // to be positive, are cut into six 7-bit digits plus a constant 1 (which counts a column's rows,
@@ -960,7 +1028,16 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
     __syncthreads();  // the margins are reused by the next panel
   }
   static_assert(kWarmWords == 3, "the walk above names three words");
-  if (colsums) {
+  // the workgroup's two sums, then the column sums; the global adds come last, so that nothing waits for them
+  for (int off = 32; off > 0; off >>= 1) {
+    acc0 += __shfl_down(acc0, off, 64);
+    acc1 += __shfl_down(acc1, off, 64);
+  }
+  if (lane == 0) {
+    shred[wave] = acc0;
+    shred1[wave] = acc1;
+  }
+  if (colsums && did_tile) {  // (a wave that took no tile holds zeros)
     // D of block m: this lane holds column 16 m + 4 (lane >> 4) + i, digit lane & 15, in element i.  The
     // 16 digit lanes of a column are one DPP row: they are put together there, and one lane adds the
     // column's sum to the workgroup's accumulator (sixteen lanes adding to one LDS word at once take
@@ -981,7 +1058,18 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
           if (digit == 0 && x2) atomicAdd(&wacc2[col], (unsigned long long)x2);
         }
       }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t0 = 0, t1 = 0;
+    for (int w8 = 0; w8 < kRpThreads / 64; ++w8) {
+      t0 += shred[w8];
+      t1 += shred1[w8];
+    }
+    a.partials[0 * kMaxPartialBlocks + blockIdx.x] = t0;
+    a.partials[1 * kMaxPartialBlocks + blockIdx.x] = t1;
+  }
+  if (colsums) {
     if (MODE == FWD_FTRL && a.mpart) {
       if (tid < (int)kMaskCols) {
         unsigned long long *slot = a.mpart + (size_t)(blockIdx.x % kMaskSlots) * 2 * kMaskCols;
@@ -994,26 +1082,6 @@ __global__ void __launch_bounds__(kRpThreads, 4) k_forward_rp(RpArgs a) {
       if (tid < (int)kMaskCols && wacc[tid]) atomicAdd(a.g1 + a.perm[tid], wacc[tid]);
       if (MODE == FWD_FTRL && tid < (int)kMaskCols && wacc2[tid]) atomicAdd(a.g2 + a.perm[tid], wacc2[tid]);
     }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    acc0 += __shfl_down(acc0, off, 64);
-    acc1 += __shfl_down(acc1, off, 64);
-  }
-  __syncthreads();
-  if (lane == 0) shred[wave] = acc0;
-  __syncthreads();
-  if (tid == 0) {
-    double t = 0;
-    for (int w8 = 0; w8 < kRpThreads / 64; ++w8) t += shred[w8];
-    a.partials[0 * kMaxPartialBlocks + blockIdx.x] = t;
-  }
-  __syncthreads();
-  if (lane == 0) shred[wave] = acc1;
-  __syncthreads();
-  if (tid == 0) {
-    double t = 0;
-    for (int w8 = 0; w8 < kRpThreads / 64; ++w8) t += shred[w8];
-    a.partials[1 * kMaxPartialBlocks + blockIdx.x] = t;
   }
 }
 
@@ -1066,6 +1134,17 @@ __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, cons
 static inline int wsum_grid(admm_ctx *ctx, uint64_t dim) { return grid_for(dim, 256, std::min(ctx->cu_count * 8, kMaxPartialBlocks)); }
 static inline float *wsum_blockmax(admm_ctx *ctx) { return reinterpret_cast<float *>(ctx->d_partials + 6 * (size_t)kMaxPartialBlocks); }
 
+// v[n - 1] <- max of v[0 .. n)
+__global__ void __launch_bounds__(256) k_max_fold(float *v, int n) {
+  __shared__ float sh[4];
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, v[i]);
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) v[n - 1] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
 // sweep over the row-panel copy: the whole set, or (r0, r1 on panel boundaries) a range of panels;
 // nw == 0: the caller has filled csr->d_wsum and the per-workgroup maxima itself
 static int launch_forward_panels(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
@@ -1101,6 +1180,12 @@ static int launch_forward_panels(admm_csr *csr, FwdMode mode, uint64_t r0, uint6
   a.blockmax = blockmax;
   // (the mini-batch pass keeps running maxima behind the per-workgroup ones: one per column block, one more)
   a.nblockmax = wgrid + (mode == FWD_FTRL ? (int)csr->nblocks + 1 : 0);
+  if (mode == FWD_FTRL && nw == 0) {
+    // ... and has folded the per-workgroup maxima into the last of them (k_max_fold), so that each of its
+    // many short launches reads one word for them
+    a.blockmax = blockmax + wgrid - 1;
+    a.nblockmax = 1 + (int)csr->nblocks + 1;
+  }
   a.lenbits = csr->fp_lenbits;
   a.vmax = csr->vmax;
   a.nrows = csr->nrows;
@@ -2167,6 +2252,8 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_ftrl_wsum, dim3(wgrid), dim3(256), 0, ctx->stream, z, n, reg_offset, offset, csr->d_inv, alpha, beta,
                        l1, l2, csr->d_wsum, csr->dim, blockmax);
+    ADMM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, ctx->stream, blockmax, wgrid);
     ADMM_HIP_CHECK(hipGetLastError());
   }
   TArgs fuse{};
