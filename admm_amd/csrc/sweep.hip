@@ -1419,6 +1419,7 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
     acc[c] = 0;
     if (FTRL) acc2[c] = 0;
   }
+  if (fused && threadIdx.x == 0) *reinterpret_cast<uint32_t *>(reinterpret_cast<uint16_t *>(acc2 + CB) + CB) = 0;  // the touched columns' count
   __syncthreads();
   // head: up to 3 entries before the first 4-aligned index; tail: what is left after the body
   const uint64_t body0 = (beg + 3) & ~3ull;
@@ -1484,48 +1485,73 @@ __global__ void __launch_bounds__(kTThreads) k_transposed(TArgs a) {
     // the batch's update of this cell's columns (src/ftrl.cc:76-88 summed over the batch's rows):
     // w <- the lazy weight at the batch's start, n' = n + G2, z += G1 - w (sqrt(n') - sqrt(n)) / alpha;
     // then the column's entry of the forward sweep's vector is brought up to date
-    float vmax = 0.0f;
-    for (uint32_t c = threadIdx.x; c < CB; c += kTThreads) {
+    // Two steps: every lane looks at its columns' sums (adding what the forward sweep left for a mask column)
+    // and the columns the batch touched are listed in LDS; then the list is worked off by full waves -- the
+    // update is double-precision arithmetic (two square roots, three divisions), and a batch touches a
+    // fraction of a cell's columns only.
+    uint16_t *tl = reinterpret_cast<uint16_t *>(acc2 + CB);
+    uint32_t *tcnt = reinterpret_cast<uint32_t *>(tl + CB);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t c0 = 0; c0 < CB; c0 += kTThreads) {  // (uniform trip count: the ballot below wants whole waves)
+      const uint32_t c = c0 + threadIdx.x;
       const uint64_t i = gbase + c;
-      if (i >= a.fdim) continue;
-      long long q1 = (long long)acc[c], q2 = (long long)acc2[c];
-      const uint32_t sid = a.finv ? a.finv[i] : (uint32_t)i;
-      if (a.fmpart && sid < kMaskCols) {
+      bool touched = false;
+      if (c < CB && i < a.fdim) {
+        long long q2 = (long long)acc2[c];
+        const uint32_t sid = a.finv ? a.finv[i] : (uint32_t)i;
+        if (a.fmpart && sid < kMaskCols) {
+          long long q1 = (long long)acc[c];
 #pragma unroll
-        for (int b = 0; b < kMaskSlots; ++b) {
-          long long *slot = a.fmpart + (size_t)b * 2 * kMaskCols;
-          q1 += slot[sid];
-          q2 += slot[kMaskCols + sid];
-          slot[sid] = 0;
-          slot[kMaskCols + sid] = 0;
+          for (int b = 0; b < kMaskSlots; ++b) {
+            long long *slot = a.fmpart + (size_t)b * 2 * kMaskCols;
+            q1 += slot[sid];
+            q2 += slot[kMaskCols + sid];
+            slot[sid] = 0;
+            slot[kMaskCols + sid] = 0;
+          }
+          acc[c] = (fx_t)q1;
+          acc2[c] = (fx_t)q2;
         }
+        touched = q2 != 0 || (a.fbias_blocks && i == 0);
       }
-      bool touched = q2 != 0;
+      const unsigned long long vote = __ballot(touched);
+      if (vote) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(tcnt, (uint32_t)__popcll(vote));
+        base = __shfl(base, 0, 64);
+        if (touched) tl[base + __popcll(vote & ((1ull << lane) - 1))] = (uint16_t)c;
+      }
+    }
+    __syncthreads();
+    const uint32_t ntouched = *tcnt;
+    float vmax = 0.0f;
+    for (uint32_t k = threadIdx.x; k < ntouched; k += kTThreads) {
+      const uint32_t c = tl[k];
+      const uint64_t i = gbase + c;
+      const long long q1 = (long long)acc[c], q2 = (long long)acc2[c];
+      const uint32_t sid = a.finv ? a.finv[i] : (uint32_t)i;
       double G1 = 0, G2 = 0;
-      if (touched) {
+      if (q2 != 0) {
         G1 = (double)q1 * a.finv_scale;
         G2 = (double)q2 * a.finv_scale;
       }
       if (a.fbias_blocks && i == 0) {
-        touched = true;
         for (int b = 0; b < a.fbias_blocks; ++b) {
           G1 += a.fpartials[0 * kMaxPartialBlocks + b];
           G2 += a.fpartials[1 * kMaxPartialBlocks + b];
         }
       }
-      if (touched) {
-        const float nold = a.fn[i], zold = a.fz[i], reg = a.freg[i];
-        const float wc = ftrl_weight(zold, nold, reg, a.falpha, a.fbeta, a.fl1, a.fl2);
-        const float nnew = (float)((double)nold + G2);
-        const double sigma = (sqrt((double)nnew) - sqrt((double)nold)) / (double)a.falpha;
-        const float znew = (float)((double)zold + (G1 - sigma * (double)wc));
-        a.fw[i] = wc;
-        a.fz[i] = znew;
-        a.fn[i] = nnew;
-        const float v = ftrl_weight(znew, nnew, reg, a.falpha, a.fbeta, a.fl1, a.fl2) + a.foff[i];
-        a.fwsum[sid] = v;
-        vmax = fmaxf(vmax, fabsf(v));
-      }
+      const float nold = a.fn[i], zold = a.fz[i], reg = a.freg[i];
+      const float wc = ftrl_weight(zold, nold, reg, a.falpha, a.fbeta, a.fl1, a.fl2);
+      const float nnew = (float)((double)nold + G2);
+      const double sigma = (sqrt((double)nnew) - sqrt((double)nold)) / (double)a.falpha;
+      const float znew = (float)((double)zold + (G1 - sigma * (double)wc));
+      a.fw[i] = wc;
+      a.fz[i] = znew;
+      a.fn[i] = nnew;
+      const float v = ftrl_weight(znew, nnew, reg, a.falpha, a.fbeta, a.fl1, a.fl2) + a.foff[i];
+      a.fwsum[sid] = v;
+      vmax = fmaxf(vmax, fabsf(v));
     }
     // the block's running maximum (no other workgroup writes it in this launch)
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
@@ -1740,7 +1766,8 @@ static int launch_transposed_impl(admm_csr *csr, bool ftrl_mode, uint64_t p0, ui
   // measurement aid: a gather-free run moves a known number of bytes, which calibrates the
   // hardware counters; it computes nothing useful
   a.no_gather = (getenv("ADMM_CALIBRATE_NO_GATHER") != nullptr ? 1 : 0) | (getenv("ADMM_CALIBRATE_NO_FLUSH") != nullptr ? 2 : 0);
-  const size_t lds = sizeof(fx_t) * csr->col_block * (ftrl_mode ? 2 : 1);
+  // (the fused update also lists the touched columns: 2 bytes a column and a counter)
+  const size_t lds = sizeof(fx_t) * csr->col_block * (ftrl_mode ? 2 : 1) + (fuse ? 2 * (size_t)csr->col_block + 64 : 0);
   // more than half of the CU's LDS: one workgroup per CU, so give it the full 1024 threads
   const bool big = lds > 72 * 1024;
   static bool raised[64] = {};  // per device
