@@ -1968,6 +1968,22 @@ __global__ void __launch_bounds__(256) k_axpy_coef(float *__restrict__ y, const 
   if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) *alpha = q;
 }
 
+// two vector copies in one launch (b_dst may be nullptr)
+__global__ void __launch_bounds__(256) k_copy2(float *__restrict__ a_dst, const float *__restrict__ a_src,
+                                               float *__restrict__ b_dst, const float *__restrict__ b_src, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    a_dst[i] = a_src[i];
+    if (b_dst) b_dst[i] = b_src[i];
+  }
+}
+
+static int copy2(admm_ctx *ctx, float *a_dst, const float *a_src, float *b_dst, const float *b_src, uint64_t n) {
+  hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, a_dst, a_src, b_dst, b_src, n);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
 // The newest correction pair and the four products the solver wants of it, in one pass:
 // s = x - xp, y = g - gp; partial rows 3..6 <- x.x, g.g, y.s, y.y (k_dot_row's order of additions).
 __global__ void __launch_bounds__(256) k_pair(const float *__restrict__ x, const float *__restrict__ xp,
@@ -2547,9 +2563,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   auto done = [&]() -> int {
     // remember where this solve ended
     if (gl_at_x) {
-      ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_cache_x, x, sizeof(float) * dim, hipMemcpyDeviceToDevice, ctx->stream));
-      if (offset)
-        ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_cache_off, offset, sizeof(float) * dim, hipMemcpyDeviceToDevice, ctx->stream));
+      ADMM_TRY(copy2(ctx, csr->d_cache_x, x, offset ? csr->d_cache_off : nullptr, offset, dim));
       csr->cache_has_off = offset != nullptr;
       csr->cache_loss = loss;
       csr->cache_margin = from_margins;
@@ -2569,8 +2583,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
   double step = 1.0 / std::sqrt(gg);
   int dg_row = -1;  // scalar slot holding g . d for the next line search, when the device has it
   for (int it = 0; it < P.max_iter; ++it) {
-    ADMM_TRY(admm_vec_copy(ctx, xp, x, dim));
-    ADMM_TRY(admm_vec_copy(ctx, gp, g, dim));
+    ADMM_TRY(copy2(ctx, xp, x, gp, g, dim));
     const double fp = f, lossp = loss;
     double dginit = 0;
     if (dg_row >= 0) {  // the two-loop recursion's last step left g . d on the device
@@ -2645,8 +2658,7 @@ extern "C" int admm_lbfgs_solve(admm_csr *csr, float *x, const float *offset, co
       if (!ok) break;
     } else if (!ok) {
       if (f > fp) {
-        ADMM_TRY(admm_vec_copy(ctx, x, xp, dim));
-        ADMM_TRY(admm_vec_copy(ctx, g, gp, dim));
+        ADMM_TRY(copy2(ctx, x, xp, g, gp, dim));
         f = fp;
         loss = lossp;
         gl_at_x = false;  // the kept loss gradient belongs to the rejected trial point
