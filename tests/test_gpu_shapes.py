@@ -1,6 +1,8 @@
 """The two training paths over a spread of shapes drawn from fixed seeds -- rows that do not fill a
 panel, dims below and above the hot stream's 8192 ids, very short and long rows, mini-batches of
 256 .. 2048 rows, column blocks of 64 .. 4096 -- each checked against the CPU restatement."""
+import os
+
 import numpy as np
 import pytest
 
@@ -31,7 +33,7 @@ def draw(seed):
     return rng, dim, nrows, mean, binary, relabel
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADMM_SHAPE_SEEDS", "10"))))
 def test_objective_and_gradient_over_shapes(ctx, oracle, seed):
     rng, dim, nrows, mean, binary, relabel = draw(seed)
     raw = make_synth_csr(nrows, dim, mean, seed=seed, binary=binary, label01=bool(seed % 2))
@@ -57,7 +59,7 @@ def test_objective_and_gradient_over_shapes(ctx, oracle, seed):
     dev.destroy()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADMM_SHAPE_SEEDS", "8"))))
 def test_minibatch_pass_over_shapes(ctx, oracle, seed):
     rng, dim, nrows, mean, binary, relabel = draw(100 + seed)
     batch = int(rng.choice([256, 512, 768, 2048]))
