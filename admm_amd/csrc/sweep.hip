@@ -740,6 +740,8 @@ __global__ void __launch_bounds__(kRpThreads, MODE == FWD_FTRL ? 2 : 4) k_forwar
     hot[j] = HASVAL ? x : truncf(x * scale);
   }
   if (tid == 0) hot[a.nhot] = 0.0f;
+  // the margins start at zero; every epilogue leaves the rows it has read at zero again
+  for (uint32_t r = tid; r < R; r += kRpThreads) rp_acc[r] = 0ull;
   if (tid < (int)kMaskCols) {
     wacc[tid] = 0ull;
     if (MODE == FWD_FTRL) wacc2[tid] = 0ull;
@@ -823,10 +825,9 @@ __global__ void __launch_bounds__(kRpThreads, MODE == FWD_FTRL ? 2 : 4) k_forwar
             }
           }
         }
-        rp_acc[r] = rp_to_fx(m0, scale);
+        atomicAdd(&rp_acc[r], rp_to_fx(m0, scale));  // (an add like all the others: no barrier before the streams)
       }
     }
-    __syncthreads();
     // the first four list entries of each lane are asked for now: they arrive while the hot stream is walked
     const bool first = p == p_first;
     const uint64_t beg = first ? pre_f0 : a.fptr[p], end = first ? pre_f1 : a.fptr[p + 1];
@@ -1024,6 +1025,7 @@ __global__ void __launch_bounds__(kRpThreads, MODE == FWD_FTRL ? 2 : 4) k_forwar
           }
         }
       }
+      rp_acc[rb + lane] = 0ull;  // (also wipes the digit planes the column sums kept there)
     }
     __syncthreads();  // the margins are reused by the next panel
   }
