@@ -175,6 +175,18 @@ class Worker:
             self.load = False
         return dict(evals=len(train_parts))
 
+    def BiasUpdate(self, train_parts, admm_params):
+        """src/workers.cc:89-113 (its call is commented out in the reference's main loop,
+        src/admm_allreduce.cpp:65): one FTRL pass from zero state with l_2 = 200, l_1 = 1000, the base
+        model as the fixed offset, no proximal centre; bias_vec_ <- the pass's weights."""
+        assert admm_params.local_solver != "lbfgs", "the bias model is an FTRL model"
+        fdim = self.base_vec_.n
+        w, z, n, zero = (self.ctx.vec(fdim) for _ in range(4))
+        for part in train_parts:
+            part.ftrl_pass(w, z, n, self.base_vec_, zero, admm_params.ftrl_alpha, 1.0, 1000.0, 200.0,
+                           batch=admm_params.ftrl_batch)
+        self.bias_vec_.copy_from(w)
+
     def LangrangeUpdate(self, admm_params, global_weights):
         """src/workers.cc:115-119"""
         self.ctx.dual_update(self.langr_vec_, self.base_vec_, global_weights, admm_params.step_size)

@@ -223,8 +223,10 @@ class Worker {
   virtual ~Worker() {}
   void InitWorker(std::size_t fdim);
   void BaseUpdate(SampleSet &train_set, SampleSet &test_set, const AdmmConfig &admm_params);
+  void BiasUpdate(SampleSet &train_set, SampleSet &test_set, const AdmmConfig &admm_params);
   void LangrangeUpdate(const AdmmConfig &admm_params);
   void GetWeights(AdmmConfig &admm_params, DeviceVector &out) const;
+  void LoadParts(const AdmmConfig &admm_params);
   // resident training parts (parsed once, not once per iteration as the reference does)
   std::vector<std::unique_ptr<SampleSet>> parts_;
   admm_lbfgs_result last_solve_ = {0, 0, 0, 0, 0};

@@ -52,8 +52,8 @@ void Worker::InitWorker(std::size_t fdim) {
   load = false;
 }
 
-// The x-update (src/workers.cc:51-87).  Parts are loaded on the first call and stay resident.
-void Worker::BaseUpdate(SampleSet &, SampleSet &test_set, const AdmmConfig &admm_params) {
+// the worker's data parts: loaded on the first call, resident afterwards
+void Worker::LoadParts(const AdmmConfig &admm_params) {
   if (parts_.empty()) {
     const std::string train_name = admm_params.train_path + "/" + psid_ + "_aggregated/part-00000";
     // The batch objective of the lbfgs solver is a sum over all rows, whatever the file's partition:
@@ -69,6 +69,30 @@ void Worker::BaseUpdate(SampleSet &, SampleSet &test_set, const AdmmConfig &admm
         parts_.back()->PrepareTransposed(admm_params.ftrl_batch, 0, true);
     }
   }
+}
+
+// The per-worker bias model (src/workers.cc:89-113; the reference's main loop has its call commented out,
+// src/admm_allreduce.cpp:65): one FTRL pass from zero state with l_2 = 200, l_1 = 1000, the base model as
+// the fixed offset and no proximal centre; bias_vec_ <- the pass's weights.  It reads the worker's
+// resident parts (the reference builds its file name without the '/' after train_path, :101, so there the
+// call only finds its data when train_path ends in one).
+void Worker::BiasUpdate(SampleSet &, SampleSet &test_set, const AdmmConfig &admm_params) {
+  ADMM_CHECK(admm_params.local_solver != "lbfgs");  // the bias model is an FTRL model
+  LoadParts(admm_params);
+  FtrlConfig ftrl_params(admm_params);
+  ftrl_params.l_2 = 200;
+  ftrl_params.l_1 = 1000;
+  ftrl_params.ftrl_batch = admm_params.ftrl_batch;
+  ::ftrl::FtrlSolver ftrl_processor;
+  ftrl_processor.Init(ftrl_params);
+  DeviceVector reg_offset(base_vec_.size());  // zero-filled
+  for (auto &part : parts_) ftrl_processor.Run(*part, test_set, base_vec_, reg_offset);
+  bias_vec_ = ftrl_processor.weight_;
+}
+
+// The x-update (src/workers.cc:51-87).  Parts are loaded on the first call and stay resident.
+void Worker::BaseUpdate(SampleSet &, SampleSet &test_set, const AdmmConfig &admm_params) {
+  LoadParts(admm_params);
   if (admm_params.local_solver == "lbfgs") {
     // batch objective: logistic loss + y.(x - z) + rho/2 |x - z|^2, warm-started at the last x
     ADMM_CHECK(parts_.size() == 1);

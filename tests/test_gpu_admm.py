@@ -156,3 +156,32 @@ def test_rccl_binding_selftest_and_loop_with_residual_tail(ctx, oracle):
         assert s2 == pytest.approx(r["residuals"][0][1], rel=1e-4, abs=1e-14)
     train.destroy()
     test.destroy()
+
+
+@pytest.mark.parametrize("batch", [1, 512])
+def test_bias_update_is_an_ftrl_pass_over_the_base_model(ctx, oracle, batch):
+    """Worker::BiasUpdate (src/workers.cc:89-113): zero state, l_2 = 200, l_1 = 1000, offset = the base
+    model, no proximal centre; the result replaces bias_vec_"""
+    from admm_amd import driver
+    dim = 400
+    raw = make_synth_csr(3000, dim, 12, seed=71)
+    raw.label[:] = 1.0                 # with the bias weight below every gradient is close to -1, so that the
+    tr = oracle.translate(raw)         # frequent columns' z leave the [-1000, 1000] band in which the weight is 0
+    rng = np.random.default_rng(5)
+    base = rng.normal(0, 0.3, dim).astype(np.float32)
+    base[0] = -6.0
+    prm = driver.AdmmConfig()
+    prm.dim, prm.ftrl_alpha, prm.ftrl_batch, prm.local_solver = dim, 0.05, batch, "ftrl"
+    wk = driver.Worker(ctx)
+    wk.InitWorker(dim)
+    wk.base_vec_.upload(base)
+    dev = ctx.csr_upload(raw.rowptr, raw.col, raw.val, raw.label, dim, add_bias=True)
+    if batch > 1:
+        dev.build_transposed(panel_rows=batch, col_block=128)
+    wk.BiasUpdate([dev], prm)
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    oracle.ftrl_run(tr, hw, hz, hn, base, np.zeros(dim, np.float32), 0.05, 1.0, 1000.0, 200.0, batch=batch)
+    assert np.count_nonzero(hw) >= 1
+    np.testing.assert_allclose(wk.bias_vec_.download(), hw, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(wk.base_vec_.download(), base)     # the base model is only read
+    dev.destroy()
