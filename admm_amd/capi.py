@@ -21,7 +21,7 @@ SYMBOLS = [
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
     "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_layout_bytes", "admm_csr_layout_counts",
     "admm_csr_destroy",
-    "admm_predict", "admm_metrics", "admm_auc_scores", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
+    "admm_predict", "admm_metrics", "admm_auc_scores", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_predict", "admm_ftrl_update", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus", "admm_consensus_static",
     "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32", "admm_comm_selftest",
 ]
@@ -98,6 +98,8 @@ def load():
         "admm_csr_copy_labels": [vp, vp],
         "admm_ftrl_pass": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, u64],
         "admm_ftrl_pass_multi": [vp, vp, vp, vp, vp, vp, C.c_int, f32, f32, f32, f32],
+        "admm_ftrl_predict": [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, f32, f32, f32, f32, C.POINTER(C.c_float)],
+        "admm_ftrl_update": [vp, vp, C.c_uint32, f32, f32, vp, vp, vp, f32],
         "admm_logistic_fg": [vp, vp, vp, vp, vp, f32, C.POINTER(C.c_double), vp],
         "admm_lbfgs_solve": [vp, vp, vp, vp, vp, f32, C.POINTER(LbfgsParams),
                              C.POINTER(LbfgsResult)],
@@ -244,6 +246,22 @@ class Context:
         _check(self.L.admm_ftrl_pass_multi(arr(sets, lambda s: s.h), arr(w, lambda v: v.ptr), arr(z, lambda v: v.ptr),
                                            arr(n, lambda v: v.ptr), arr(offset, lambda v: v.ptr),
                                            arr(reg_offset, lambda v: v.ptr), cnt, alpha, beta, l_1, l_2))
+
+    def ftrl_predict(self, index, value, w, z, n, offset, reg_offset, alpha, beta, l_1, l_2):
+        """FtrlSolver::Predict (src/ftrl.cc:54-73) on one translated row held in host arrays (value None: all
+        ones): refreshes w at the row's coordinates and returns P(y = 1)"""
+        idx = np.ascontiguousarray(index, np.uint32)
+        val = None if value is None else np.ascontiguousarray(value, np.float32)
+        p = C.c_float()
+        _check(self.L.admm_ftrl_predict(self.h, _ptr(idx), None if val is None else _ptr(val), idx.shape[0], w.ptr,
+                                        z.ptr, n.ptr, offset.ptr, reg_offset.ptr, alpha, beta, l_1, l_2, C.byref(p)))
+        return float(p.value)
+
+    def ftrl_update(self, index, label, predict, w, z, n, alpha):
+        """FtrlSolver::Update (src/ftrl.cc:75-88) on the same row"""
+        idx = np.ascontiguousarray(index, np.uint32)
+        _check(self.L.admm_ftrl_update(self.h, _ptr(idx), idx.shape[0], float(label), float(predict), w.ptr, z.ptr,
+                                       n.ptr, alpha))
 
     # consensus algebra --------------------------------------------------------------------
     def payload(self, x, ydual, rho, out):

@@ -455,6 +455,7 @@ extern "C" int admm_ctx_destroy(admm_ctx *ctx) {
   if (ctx->lbfgs_ws) hipFree(ctx->lbfgs_ws);
   if (ctx->d_multi) hipFree(ctx->d_multi);
   if (ctx->auc_ws) hipFree(ctx->auc_ws);
+  if (ctx->row_ws) hipFree(ctx->row_ws);
   if (ctx->d_lb) hipFree(ctx->d_lb);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -497,3 +497,116 @@ int ftrl_pass_multi(admm_csr *const *sets, float *const *w, float *const *z, flo
 }
 
 }  // namespace admm_impl
+
+// ---- one row at a time (FtrlSolver::Predict / Update as calls of their own) -----------------------
+
+namespace admm_impl {
+
+struct RowArgs {
+  const uint32_t *idx;
+  const float *val;
+  uint32_t len;
+  float *w, *z, *n;
+  const float *offset, *reg;
+  float alpha, beta, l1, l2, label, predict;
+  float *p_out;
+};
+
+// src/ftrl.cc:57-72, one lane, element by element as there
+__global__ void __launch_bounds__(64) k_ftrl_row_predict(RowArgs a) {
+  if (threadIdx.x != 0) return;
+  for (uint32_t k = 0; k < a.len; ++k) {
+    const uint32_t j = a.idx[k];
+    a.w[j] = seq_weight(a.z[j], a.n[j], a.reg[j], a.alpha, a.beta, a.l1, a.l2);
+  }
+  float sw = 0.0f, so = 0.0f;
+  for (uint32_t k = 0; k < a.len; ++k) {
+    const uint32_t j = a.idx[k];
+    const float v = a.val ? a.val[k] : 1.0f;
+    sw += a.w[j] * v;
+    so += a.offset[j] * v;
+  }
+  *a.p_out = seq_sigmoid(sw + so);
+}
+
+// src/ftrl.cc:76-87
+__global__ void __launch_bounds__(64) k_ftrl_row_update(RowArgs a) {
+  if (threadIdx.x != 0) return;
+  const int y = a.label > 0 ? 1 : 0;
+  const float g = a.predict - y;
+  for (uint32_t k = 0; k < a.len; ++k) {
+    const uint32_t j = a.idx[k];
+    const double sigma = (sqrt((double)(a.n[j] + g * g)) - sqrt((double)a.n[j])) / (double)a.alpha;
+    a.z[j] = (float)((double)a.z[j] + ((double)g - sigma * (double)a.w[j]));
+    a.n[j] = a.n[j] + g * g;
+  }
+}
+
+// the row's entries in the context's scratch: [p_out | idx[len] | val[len]]
+static int stage_row(admm_ctx *ctx, const uint32_t *index, const float *value, uint32_t length, RowArgs *a) {
+  const size_t need = 256 + (sizeof(uint32_t) + sizeof(float)) * (size_t)length;
+  if (ctx->row_ws_bytes < need) {
+    ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->row_ws) ADMM_HIP_CHECK(hipFree(ctx->row_ws));
+    ctx->row_ws = nullptr;
+    ctx->row_ws_bytes = 0;
+    ADMM_HIP_CHECK(hipMalloc(&ctx->row_ws, need * 2));
+    ctx->row_ws_bytes = need * 2;
+  }
+  char *base = static_cast<char *>(ctx->row_ws);
+  a->p_out = reinterpret_cast<float *>(base);
+  uint32_t *didx = reinterpret_cast<uint32_t *>(base + 256);
+  float *dval = reinterpret_cast<float *>(base + 256 + sizeof(uint32_t) * (size_t)length);
+  if (length) {
+    ADMM_HIP_CHECK(hipMemcpyAsync(didx, index, sizeof(uint32_t) * length, hipMemcpyHostToDevice, ctx->stream));
+    if (value) ADMM_HIP_CHECK(hipMemcpyAsync(dval, value, sizeof(float) * length, hipMemcpyHostToDevice, ctx->stream));
+  }
+  a->idx = didx;
+  a->val = value ? dval : nullptr;
+  a->len = length;
+  return ADMM_OK;
+}
+
+}  // namespace admm_impl
+
+extern "C" int admm_ftrl_predict(admm_ctx *ctx, const uint32_t *index, const float *value, uint32_t length, float *w,
+                                 const float *z, const float *n, const float *offset, const float *reg_offset,
+                                 float alpha, float beta, float l1, float l2, float *p_out) {
+  ADMM_REQUIRE(ctx && w && z && n && offset && reg_offset && p_out && (index || length == 0),
+               "admm_ftrl_predict: NULL argument");
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  admm_impl::RowArgs a{};
+  ADMM_TRY(admm_impl::stage_row(ctx, index, value, length, &a));
+  a.w = w;
+  a.z = const_cast<float *>(z);
+  a.n = const_cast<float *>(n);
+  a.offset = offset;
+  a.reg = reg_offset;
+  a.alpha = alpha;
+  a.beta = beta;
+  a.l1 = l1;
+  a.l2 = l2;
+  hipLaunchKernelGGL(admm_impl::k_ftrl_row_predict, dim3(1), dim3(64), 0, ctx->stream, a);
+  ADMM_HIP_CHECK(hipGetLastError());
+  ADMM_HIP_CHECK(hipMemcpyAsync(p_out, a.p_out, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (also: the caller's arrays are free again)
+  return ADMM_OK;
+}
+
+extern "C" int admm_ftrl_update(admm_ctx *ctx, const uint32_t *index, uint32_t length, float label, float predict,
+                                const float *w, float *z, float *n, float alpha) {
+  ADMM_REQUIRE(ctx && w && z && n && (index || length == 0), "admm_ftrl_update: NULL argument");
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  admm_impl::RowArgs a{};
+  ADMM_TRY(admm_impl::stage_row(ctx, index, nullptr, length, &a));
+  a.w = const_cast<float *>(w);
+  a.z = z;
+  a.n = n;
+  a.alpha = alpha;
+  a.label = label;
+  a.predict = predict;
+  hipLaunchKernelGGL(admm_impl::k_ftrl_row_update, dim3(1), dim3(64), 0, ctx->stream, a);
+  ADMM_HIP_CHECK(hipGetLastError());
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ADMM_OK;
+}

@@ -88,6 +88,8 @@ struct admm_ctx {
   float *lbfgs_ws = nullptr;
   uint64_t lbfgs_ws_floats = 0;
   // AUC workspace (sort keys, flags, rank starts, the sort's own scratch); grows, never shrinks
+  void *row_ws = nullptr;  // one row's entries for admm_ftrl_predict / admm_ftrl_update (grow-only)
+  size_t row_ws_bytes = 0;
   void *auc_ws = nullptr;
   size_t auc_ws_bytes = 0;
   // device scalars of the L-BFGS two-loop recursion (see admm_lbfgs_solve)

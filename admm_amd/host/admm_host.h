@@ -201,6 +201,10 @@ class FtrlSolver {
   // one pass over train_set (FtrlSolver::Run, src/ftrl.cc:101-145); test_set is unused, as there
   void Run(SampleSet &train_set, SampleSet &test_set, const ::admm::DeviceVector &offset,
            const ::admm::DeviceVector &reg_offset);
+  // one row at a time, as FtrlSolver::Run does inside (src/ftrl.cc:54-88): x is a translated row
+  // (SampleSet::TranslateData); one launch and one host wait per call
+  real_t Predict(::admm::Row &x, const ::admm::DeviceVector &offset, const ::admm::DeviceVector &reg_offset);
+  void Update(real_t predict, const ::admm::Row &x, const ::admm::DeviceVector &reg_offset);
   ::admm::DeviceVector weight() const { return weight_; }
 
   ::admm::DeviceVector weight_, mid_weight_, squared_sum_;

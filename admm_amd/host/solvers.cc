@@ -32,6 +32,32 @@ void FtrlSolver::Assign(const DeviceVector &x, const DeviceVector &y) {
   squared_sum_ = y;
 }
 
+// src/ftrl.cc:54-73
+FtrlSolver::real_t FtrlSolver::Predict(::admm::Row &x, const DeviceVector &offset, const DeviceVector &reg_offset) {
+  ADMM_CHECK(offset.size() == dim_ && reg_offset.size() == dim_);
+  std::vector<uint32_t> index(x.length);
+  for (size_t i = 0; i < x.length; ++i) {
+    ADMM_CHECK(x.index[i] < dim_);
+    index[i] = (uint32_t)x.index[i];
+  }
+  float p = 0;
+  ADMM_CALL(admm_ftrl_predict(::admm::Runtime::Get().ctx(), index.data(), x.value, (uint32_t)x.length, weight_.data(),
+                              mid_weight_.data(), squared_sum_.data(), offset.data(), reg_offset.data(), alpha_, beta_,
+                              l_1_, l_2_, &p));
+  return p;
+}
+
+// src/ftrl.cc:75-88
+void FtrlSolver::Update(real_t predict, const ::admm::Row &x, const DeviceVector &) {
+  std::vector<uint32_t> index(x.length);
+  for (size_t i = 0; i < x.length; ++i) {
+    ADMM_CHECK(x.index[i] < dim_);
+    index[i] = (uint32_t)x.index[i];
+  }
+  ADMM_CALL(admm_ftrl_update(::admm::Runtime::Get().ctx(), index.data(), (uint32_t)x.length, x.label, predict,
+                             weight_.data(), mid_weight_.data(), squared_sum_.data(), alpha_));
+}
+
 void FtrlSolver::Run(SampleSet &train_set, SampleSet &, const DeviceVector &offset, const DeviceVector &reg_offset) {
   ADMM_CHECK(train_set.device() != nullptr);
   ADMM_CHECK(offset.size() == dim_ && reg_offset.size() == dim_);

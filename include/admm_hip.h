@@ -167,6 +167,18 @@ int admm_ftrl_pass(admm_csr *csr, float *w, float *z, float *n, const float *off
                    const float *reg_offset, float alpha, float beta, float l1, float l2,
                    uint64_t batch);
 
+/* FtrlSolver::Predict (src/ftrl.cc:54-73) on one translated row given as HOST arrays (index[length],
+ * value[length] or NULL for all ones): refreshes w at the row's coordinates from z, n, reg_offset and
+ * returns P(y = 1) through p_out (host).  FtrlSolver::Update (src/ftrl.cc:75-88): z, n at the row's
+ * coordinates from the prediction and the label.  Run is the two in turn for every row; these exist for
+ * callers that drive the solver row by row as the reference's tests do -- one launch and one host wait per
+ * call, nothing to measure. */
+int admm_ftrl_predict(admm_ctx *ctx, const uint32_t *index, const float *value, uint32_t length, float *w,
+                      const float *z, const float *n, const float *offset, const float *reg_offset, float alpha,
+                      float beta, float l1, float l2, float *p_out);
+int admm_ftrl_update(admm_ctx *ctx, const uint32_t *index, uint32_t length, float label, float predict,
+                     const float *w, float *z, float *n, float alpha);
+
 /* `count` independent sequential passes (admm_ftrl_pass with batch == 1) in one launch: pass k
  * runs sample set sets[k] with its own state w[k], z[k], n[k] and its own offset[k] /
  * reg_offset[k] (which may be shared between passes; the state vectors may not).  This is

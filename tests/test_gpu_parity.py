@@ -741,3 +741,39 @@ def test_rows_longer_than_a_staging_pass(ctx, oracle, relabel):
     s64, p_ref = oracle.logloss_sum_f64(tr, [x], want_p=True)
     close(dev.predict([ctx.vec(dim, x)]), p_ref, atol=1e-6)
     dev.destroy()
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_predict_and_update_row_by_row_equal_the_pass(ctx, oracle, binary):
+    """FtrlSolver::Run is Predict then Update for every row and one more Predict on the last row
+    (src/ftrl.cc:101-145): driving the two entry points row by row from the host gives the state of
+    admm_ftrl_pass(batch = 1) (up to the order in which a row's products are added: element by element
+    here, as the reference does, across the wavefront in the pass); at zero state a prediction is 0.5
+    (test/ftrl_test.cc:37)"""
+    dim = 300
+    raw = make_synth_csr(400, dim, 9, seed=91, binary=binary)
+    tr = oracle.translate(raw)
+    rng = np.random.default_rng(2)
+    off = rng.normal(0, 0.05, dim).astype(np.float32)
+    reg = rng.normal(0, 0.05, dim).astype(np.float32)
+    prm = (0.1, 1.0, 0.05, 0.5)
+    w, z, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    zero = ctx.vec(dim)
+    doff, dreg = ctx.vec(dim, off), ctx.vec(dim, reg)
+    rows = [(tr.col[int(tr.rowptr[r]):int(tr.rowptr[r + 1])], tr.val[int(tr.rowptr[r]):int(tr.rowptr[r + 1])])
+            for r in range(tr.nrows)]
+    assert ctx.ftrl_predict(rows[0][0], rows[0][1], w, z, n, zero, zero, *prm) == 0.5
+    for r, (idx, val) in enumerate(rows):
+        p = ctx.ftrl_predict(idx, None if binary else val, w, z, n, doff, dreg, *prm)
+        ctx.ftrl_update(idx, tr.label[r], p, w, z, n, prm[0])
+    ctx.ftrl_predict(rows[-1][0], None if binary else rows[-1][1], w, z, n, doff, dreg, *prm)
+    dev = upload(ctx, raw, dim)
+    w2, z2, n2 = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    dev.ftrl_pass(w2, z2, n2, doff, dreg, *prm)
+    for a, b in ((w, w2), (z, z2), (n, n2)):
+        close(a.download(), b.download(), rtol=1e-5, atol=1e-7)
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    oracle.ftrl_run(tr, hw, hz, hn, off, reg, *prm)
+    for got, ref in ((w, hw), (z, hz), (n, hn)):
+        close(got.download(), ref, rtol=1e-5, atol=1e-7)
+    dev.destroy()
