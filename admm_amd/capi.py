@@ -21,7 +21,7 @@ SYMBOLS = [
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
     "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_layout_bytes", "admm_csr_layout_counts",
     "admm_csr_destroy",
-    "admm_predict", "admm_metrics", "admm_auc_scores", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_predict", "admm_ftrl_update", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
+    "admm_predict", "admm_metrics", "admm_auc_scores", "admm_tied_ranks", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_predict", "admm_ftrl_update", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus", "admm_consensus_static",
     "admm_comm_unique_id", "admm_comm_init", "admm_allreduce_sum_f32", "admm_comm_selftest",
 ]
@@ -95,6 +95,7 @@ def load():
         "admm_metrics": [vp, C.POINTER(vp), i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                          C.POINTER(u64)],
         "admm_auc_scores": [vp, vp, vp, u64, C.POINTER(C.c_double)],
+        "admm_tied_ranks": [vp, vp, u64, vp],
         "admm_csr_copy_labels": [vp, vp],
         "admm_ftrl_pass": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, u64],
         "admm_ftrl_pass_multi": [vp, vp, vp, vp, vp, vp, C.c_int, f32, f32, f32, f32],
@@ -273,6 +274,10 @@ class Context:
 
     def dual_update(self, ydual, x, z, rho):
         _check(self.L.admm_dual_update(self.h, ydual.ptr, x.ptr, z.ptr, rho, x.n))
+
+    def tied_ranks(self, scores, ranks, n=None):
+        """Metrics::Sort (src/metrics.cc:14-46) of a device vector of scores into a device vector of ranks"""
+        _check(self.L.admm_tied_ranks(self.h, scores.ptr, scores.n if n is None else int(n), ranks.ptr))
 
     def auc_scores(self, scores, labels, n):
         """tie-aware rank-sum AUC (src/metrics.cc:14-89) of n (score, label) pairs held in device vectors"""

@@ -107,6 +107,64 @@ int auc_scores(admm_ctx *ctx, const float *labels, const float *scores, uint64_t
   return ADMM_OK;
 }
 
+// rank[orig[i]] = (s + e + 1) / 2 in float arithmetic as the reference has it (src/metrics.cc:32-44), for
+// sorted position i in the tie group [s, e)
+__global__ void __launch_bounds__(256) k_rank_write(const uint32_t *__restrict__ start, const uint32_t *__restrict__ orig,
+                                                    uint64_t n, float *__restrict__ ranks) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const uint32_t s = start[i];
+    uint64_t lo = i + 1, hi = n;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (start[mid] > s) hi = mid;
+      else lo = mid + 1;
+    }
+    ranks[orig[i]] = ((float)(int)(s + (uint32_t)lo) + 1.0f) / 2;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_iota_u32(uint32_t *v, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) v[i] = (uint32_t)i;
+}
+
+// Metrics::Sort (src/metrics.cc:14-46): tied ranks, 1-based, of n scores
+int tied_ranks(admm_ctx *ctx, const float *scores, uint64_t n, float *ranks) {
+  ADMM_REQUIRE(n < 0x7FFFFFFFull, "admm_tied_ranks: up to 2^31-1 scores");
+  if (n == 0) return ADMM_OK;
+  const size_t arr = (sizeof(uint32_t) * n + 255) & ~(size_t)255;
+  size_t bytes = 0, bytes2 = 0;
+  ADMM_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, scores, (float *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (size_t)n, 0, 32, ctx->stream));
+  ADMM_HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes2, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n,
+                                         rocprim::maximum<uint32_t>(), ctx->stream));
+  if (bytes2 > bytes) bytes = bytes2;
+  if (bytes < 16) bytes = 16;
+  const size_t need = 4 * arr + bytes;
+  if (ctx->auc_ws_bytes < need) {
+    ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->auc_ws) ADMM_HIP_CHECK(hipFree(ctx->auc_ws));
+    ctx->auc_ws = nullptr;
+    ctx->auc_ws_bytes = 0;
+    ADMM_HIP_CHECK(hipMalloc(&ctx->auc_ws, need));
+    ctx->auc_ws_bytes = need;
+  }
+  char *base = static_cast<char *>(ctx->auc_ws);
+  float *keys = reinterpret_cast<float *>(base);
+  uint32_t *idx_in = reinterpret_cast<uint32_t *>(base + arr), *idx_out = reinterpret_cast<uint32_t *>(base + 2 * arr),
+           *start = reinterpret_cast<uint32_t *>(base + 3 * arr);
+  void *tmp = base + 4 * arr;
+  const int grid = grid_for(n, 256, ctx->cu_count * 8);
+  hipLaunchKernelGGL(k_iota_u32, dim3(grid), dim3(256), 0, ctx->stream, idx_in, n);
+  ADMM_HIP_CHECK(rocprim::radix_sort_pairs(tmp, bytes, scores, keys, idx_in, idx_out, (size_t)n, 0, 32, ctx->stream));
+  hipLaunchKernelGGL(k_auc_heads, dim3(grid), dim3(256), 0, ctx->stream, keys, start, n);
+  ADMM_HIP_CHECK(rocprim::inclusive_scan(tmp, bytes, start, start, (size_t)n, rocprim::maximum<uint32_t>(), ctx->stream));
+  hipLaunchKernelGGL(k_rank_write, dim3(grid), dim3(256), 0, ctx->stream, start, idx_out, n, ranks);
+  ADMM_HIP_CHECK(hipGetLastError());
+  return ADMM_OK;
+}
+
 int auc_device(admm_csr *csr, const float *scores, double *auc_out) {
   return auc_scores(csr->ctx, csr->d_label, scores, csr->nrows, auc_out);
 }
@@ -117,6 +175,12 @@ extern "C" int admm_auc_scores(admm_ctx *ctx, const float *scores, const float *
   ADMM_REQUIRE(ctx && auc && (n == 0 || (scores && labels)), "admm_auc_scores: NULL argument");
   ADMM_HIP_CHECK(hipSetDevice(ctx->device));
   return admm_impl::auc_scores(ctx, labels, scores, n, auc);
+}
+
+extern "C" int admm_tied_ranks(admm_ctx *ctx, const float *scores, uint64_t n, float *ranks) {
+  ADMM_REQUIRE(ctx && (n == 0 || (scores && ranks)), "admm_tied_ranks: NULL argument");
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  return admm_impl::tied_ranks(ctx, scores, n, ranks);
 }
 
 extern "C" int admm_csr_copy_labels(admm_csr *csr, float *dst) {

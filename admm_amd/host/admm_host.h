@@ -258,6 +258,8 @@ class Master {
 class Metrics {
  public:
   typedef float real_t;
+  // tied rank function (src/metrics.cc:14-46), computed on the device
+  void Sort(const std::vector<real_t> &input, std::vector<real_t> &output);
   real_t Auc(::admm::SampleSet &sample_set, std::vector<const ::admm::DeviceVector *> &weights, bool T);
   real_t LogLoss(::admm::SampleSet &sample_set, std::vector<const ::admm::DeviceVector *> &weights, bool T);
   // both in one sweep

@@ -228,6 +228,16 @@ void Metrics::AllRanks(::admm::Runtime &rt, ::admm::SampleSet &sample_set, std::
   if (rows) *rows = total;
 }
 
+// src/metrics.cc:14-46
+void Metrics::Sort(const std::vector<real_t> &input, std::vector<real_t> &output) {
+  output.assign(input.size(), 0);
+  if (input.empty()) return;
+  DeviceVector scores(input.size()), ranks(input.size());
+  scores.from_host(input);
+  ADMM_CALL(admm_tied_ranks(::admm::Runtime::Get().ctx(), scores.data(), input.size(), ranks.data()));
+  output = ranks.to_host();
+}
+
 Metrics::real_t Metrics::Auc(::admm::SampleSet &sample_set, std::vector<const DeviceVector *> &weights, bool) {
   real_t a = 0;
   Both(sample_set, weights, nullptr, &a);

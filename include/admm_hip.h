@@ -144,6 +144,9 @@ int admm_predict(admm_csr *csr, const float *const *groups, int ngroups, float *
  * on the device in double.  Either output pointer may be NULL. */
 int admm_metrics(admm_csr *csr, const float *const *groups, int ngroups, double *logloss_mean,
                  double *auc, uint64_t *nrows);
+/* Metrics::Sort (src/metrics.cc:14-46): the tied ranks (1-based, a tie group shares the mean of its ranks,
+ * computed in float as there) of n scores; scores and ranks are DEVICE arrays, n < 2^31. */
+int admm_tied_ranks(admm_ctx *ctx, const float *scores, uint64_t n, float *ranks);
 /* Metrics::Auc + Metrics::Sort (src/metrics.cc:14-89) on bare arrays: the same tie-aware rank-sum
  * AUC over n (score, label) pairs in DEVICE memory.  The reference reports one AUC per rank; a
  * job that wants the AUC of all ranks' test rows together gathers the ranks' scores and labels

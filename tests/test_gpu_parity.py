@@ -777,3 +777,17 @@ def test_predict_and_update_row_by_row_equal_the_pass(ctx, oracle, binary):
     for got, ref in ((w, hw), (z, hz), (n, hn)):
         close(got.download(), ref, rtol=1e-5, atol=1e-7)
     dev.destroy()
+
+
+def test_tied_ranks_are_the_reference_sort(ctx, oracle):
+    """Metrics::Sort (src/metrics.cc:14-46): ties share the mean of their 1-based ranks; negative, zero,
+    repeated and single scores"""
+    rng = np.random.default_rng(8)
+    for n in (1, 2, 7, 1000, 70001):
+        x = np.round(rng.normal(0, 1, n), 1).astype(np.float32)      # many ties
+        if n > 2:
+            x[:3] = [0.0, -0.0, 0.0]
+        ranks = ctx.vec(n)
+        ctx.tied_ranks(ctx.vec(n, x), ranks)
+        np.testing.assert_array_equal(ranks.download(), oracle.tied_rank(x))
+    np.testing.assert_array_equal(oracle.tied_rank(np.array([3, 1, 3, 2], np.float32)), [3.5, 1.0, 3.5, 2.0])
