@@ -109,24 +109,21 @@ int reduce_rows_queue(admm_ctx *ctx, int first, int count, int split, int nblock
   return ADMM_OK;
 }
 
-// until ctx->h_scalars holds what the last queued reduction wrote
+// until ctx->h_scalars holds what the last queued reduction wrote.  A reduction that follows short kernels
+// arrives within microseconds, and the host polls for it; after a few hundred microseconds of that (the
+// stream is in a long sweep) it waits for the stream instead, which also reports a fault on it.
 int wait_scalars(admm_ctx *ctx) {
   const unsigned long long want = ctx->seq_issued;
   volatile unsigned long long *seq = ctx->h_seq;
-  unsigned spins = 0;
-  int idle_seen = 0;
-  while (*seq < want) {
-    if ((++spins & 0x3FFFu) == 0) {  // a fault on the stream must not leave the host spinning
-      const hipError_t e = hipStreamQuery(ctx->stream);
-      if (e != hipSuccess && e != hipErrorNotReady) {
-        set_error("wait_scalars: %s", hipGetErrorString(e));
-        return ADMM_ERR_HIP;
-      }
-      if (e == hipSuccess && *seq < want && ++idle_seen > 4) {
+  for (unsigned spins = 0; *seq < want; ++spins) {
+    if (spins == 4096) {
+      ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (*seq < want) {
         set_error("wait_scalars: the stream is idle and reduction %llu has not arrived (at %llu)", want,
                   (unsigned long long)*seq);
         return ADMM_ERR_HIP;
       }
+      break;
     }
 #if !defined(__HIP_DEVICE_COMPILE__)
     __builtin_ia32_pause();
