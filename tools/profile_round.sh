@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one round on the GPU box into gpurun_out/prof_<tag>/:
-# kernel statistics of the three bench configurations, separate FETCH_SIZE / WRITE_SIZE counter
+# kernel statistics of the three bench configurations (and of a shard of 8 of the default one), separate FETCH_SIZE / WRITE_SIZE counter
 # passes over one step of the default configuration, and the calibration of FETCH_SIZE for 2-, 4-,
 # 8- and 16-byte-per-lane streaming reads (tools/fetch_size_calib.hip, built beforehand).
 #   tools/profile_round.sh <tag>
@@ -22,6 +22,10 @@ done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_explicit" -o bench -- \
   python3 "$root/bench.py" --explicit-values --rows 50000000 --steps 2 --warmup 1 --no-cpu-baseline --no-other-linesearch > "$out/bench_explicit_line.json" 2> "$out/bench_explicit_stats.err"
 echo "stats explicit done"
+# one rank's share of the default workload on 8 GPUs, on this one GPU
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_shard8" -o bench -- \
+  python3 "$root/bench.py" --rows 12500000 --steps 8 --warmup 2 --no-cpu-baseline --no-other-linesearch > "$out/bench_shard8_line.json" 2> "$out/bench_shard8_stats.err"
+echo "stats shard-of-8 done"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o pmc -- \
   python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_fetch_line.json" 2> "$out/pmc_fetch.err"
 echo "fetch done"
