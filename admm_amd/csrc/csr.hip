@@ -1331,6 +1331,52 @@ static void free_csr(admm_csr *c) {
 // C ABI
 // =============================================================================================
 
+namespace admm_impl {
+
+// What admm_csr_upload checks, on the device (the arrays are there anyway, and a host loop over 10^10 entries
+// would take longer than their transfer): row pointers that decrease or leave [0, nnz], feature indices
+// beyond `limit`, a value other than 1, a row that stores a column twice.  One 16-lane group per row.  Rows
+// whose indices increase strictly (what libsvm files hold) need no pairwise comparison.
+struct UploadFlags {
+  unsigned long long bad_row;  // smallest offending row, ~0 if none
+  unsigned int dup, nonunit;
+};
+
+__global__ void __launch_bounds__(256) k_validate(const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                  const float *__restrict__ val, uint64_t nrows, uint64_t nnz,
+                                                  uint64_t limit, UploadFlags *__restrict__ f) {
+  const int sub = threadIdx.x & 15;
+  const uint64_t grp = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const uint64_t ngrp = ((uint64_t)gridDim.x * 256) >> 4;
+  for (uint64_t r = grp; r < nrows; r += ngrp) {
+    const uint64_t b = rowptr[r], e = rowptr[r + 1];
+    if (e < b || e > nnz) {
+      if (sub == 0) atomicMin(&f->bad_row, (unsigned long long)r);
+      continue;
+    }
+    int unsorted = 0;
+    for (uint64_t k = b + sub; k < e; k += 16) {
+      const uint32_t c = col[k];
+      if (c >= limit) atomicMin(&f->bad_row, (unsigned long long)r);
+      if (val && val[k] != 1.0f) f->nonunit = 1u;
+      if (k > b && col[k - 1] >= c) unsorted = 1;
+    }
+    for (int off = 8; off > 0; off >>= 1) unsorted |= __shfl_xor(unsorted, off, 16);
+    if (unsorted) {
+      for (uint64_t k = b + sub; k < e; k += 16) {
+        const uint32_t c = col[k];
+        for (uint64_t q = b; q < k; ++q)
+          if (col[q] == c) {
+            f->dup = 1u;
+            break;
+          }
+      }
+    }
+  }
+}
+
+}  // namespace admm_impl
+
 extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint32_t *col,
                                const float *val, const float *label, uint64_t nrows, uint64_t nnz,
                                uint64_t dim, int add_bias, admm_csr **out) {
@@ -1342,44 +1388,25 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
                (unsigned long long)dim);
   ADMM_REQUIRE(nrows < 0xFFFFFFFFull, "admm_csr_upload: at most 2^32-1 rows per sample set");
   ADMM_REQUIRE(rowptr[0] == 0 && rowptr[nrows] == nnz, "admm_csr_upload: rowptr does not span nnz");
-  // host-side validation: monotone rowptr, index range (dmlc's SDot CHECKs index < size),
-  // duplicate columns inside a row
-  bool dup = false;
   const uint64_t limit = add_bias ? dim - 1 : dim;
-  for (uint64_t r = 0; r < nrows; ++r) {
-    ADMM_REQUIRE(rowptr[r] <= rowptr[r + 1], "admm_csr_upload: rowptr decreases at row %llu",
-                 (unsigned long long)r);
-    for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-      ADMM_REQUIRE(col[k] < limit, "admm_csr_upload: feature index %u of row %llu needs dim > %llu",
-                   col[k], (unsigned long long)r, (unsigned long long)(add_bias ? col[k] + 1 : col[k]));
-      if (!dup)
-        for (uint64_t q = rowptr[r]; q < k; ++q)
-          if (col[q] == col[k]) {
-            dup = true;
-            break;
-          }
-    }
-  }
   ADMM_HIP_CHECK(hipSetDevice(ctx->device));
   admm_csr *c = new admm_csr();
   c->ctx = ctx;
   c->nrows = nrows;
   c->dim = dim;
   c->has_bias = add_bias != 0;
-  c->has_dup_cols = dup;
   c->nnz = add_bias ? nnz + nrows : nnz;
-  // a set whose stored values are all 1 (binary features, the common case for this model) is kept
-  // as a pattern matrix: no value array, the kernels read an implicit 1
-  bool unit = true;
-  if (val)
-    for (uint64_t k = 0; k < nnz; ++k)
-      if (val[k] != 1.0f) {
-        unit = false;
-        break;
-      }
-  const bool keep_val = !unit;
-  int rc = ADMM_OK;
+  // the raw arrays go to the device first (with the padding the sweeps' wide loads want), are checked
+  // there, and then either become the set's arrays or are translated into them (bias column)
+  uint64_t *t_rowptr = nullptr;
+  uint32_t *t_col = nullptr;
+  float *t_val = nullptr;
+  UploadFlags *d_flags = nullptr;
   auto fail = [&](int code) {
+    if (t_rowptr) hipFree(t_rowptr);
+    if (t_col) hipFree(t_col);
+    if (t_val) hipFree(t_val);
+    if (d_flags) hipFree(d_flags);
     free_csr(c);
     return code;
   };
@@ -1391,26 +1418,58 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
       return fail(e_ == hipErrorOutOfMemory ? ADMM_ERR_NOMEM : ADMM_ERR_HIP);              \
     }                                                                                      \
   } while (0)
-  UP_CHECK(hipMalloc(&c->d_rowptr, sizeof(uint64_t) * (nrows + 1)));
-  UP_CHECK(hipMalloc(&c->d_col, sizeof(uint32_t) * (c->nnz + 8)));
-  if (keep_val) UP_CHECK(hipMalloc(&c->d_val, sizeof(float) * (c->nnz + 8)));
+  UP_CHECK(hipMalloc(&t_rowptr, sizeof(uint64_t) * (nrows + 1)));
+  UP_CHECK(hipMalloc(&t_col, sizeof(uint32_t) * (nnz + 8)));
+  if (val) UP_CHECK(hipMalloc(&t_val, sizeof(float) * (nnz + 8)));
+  UP_CHECK(hipMalloc(&d_flags, sizeof(UploadFlags)));
   UP_CHECK(hipMalloc(&c->d_label, sizeof(float) * std::max<uint64_t>(nrows, 1)));
+  UploadFlags flags = {~0ull, 0u, 0u};
+  UP_CHECK(hipMemcpyAsync(d_flags, &flags, sizeof(flags), hipMemcpyHostToDevice, ctx->stream));
   if (nrows) UP_CHECK(hipMemcpyAsync(c->d_label, label, sizeof(float) * nrows, hipMemcpyHostToDevice, ctx->stream));
+  UP_CHECK(hipMemcpyAsync(t_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (nnz) UP_CHECK(hipMemcpyAsync(t_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
+  if (val && nnz) UP_CHECK(hipMemcpyAsync(t_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+  if (nrows) {
+    hipLaunchKernelGGL(k_validate, dim3(grid_for(nrows * 16, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, t_rowptr,
+                       t_col, t_val, nrows, nnz, limit, d_flags);
+    UP_CHECK(hipGetLastError());
+  }
+  UP_CHECK(hipMemcpyAsync(&flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+  UP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (flags.bad_row != ~0ull) {
+    // the message names what is wrong with the first offending row (the host still holds the arrays)
+    const uint64_t r = flags.bad_row;
+    if (rowptr[r] > rowptr[r + 1] || rowptr[r + 1] > nnz) {
+      set_error("admm_csr_upload: rowptr decreases at row %llu", (unsigned long long)r);
+    } else {
+      for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+        if (col[k] >= limit) {
+          set_error("admm_csr_upload: feature index %u of row %llu needs dim > %llu", col[k], (unsigned long long)r,
+                    (unsigned long long)(add_bias ? col[k] + 1 : col[k]));
+          break;
+        }
+    }
+    return fail(ADMM_ERR_INVALID);
+  }
+  c->has_dup_cols = flags.dup != 0;
+  // a set whose stored values are all 1 (binary features, the common case for this model) is kept
+  // as a pattern matrix: no value array, the kernels read an implicit 1
+  const bool keep_val = val && flags.nonunit != 0;
+  if (!keep_val && t_val) {
+    hipFree(t_val);
+    t_val = nullptr;
+  }
   if (!add_bias) {
-    UP_CHECK(hipMemcpyAsync(c->d_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (nnz) UP_CHECK(hipMemcpyAsync(c->d_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
-    if (keep_val && nnz) UP_CHECK(hipMemcpyAsync(c->d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
-    UP_CHECK(hipStreamSynchronize(ctx->stream));
+    c->d_rowptr = t_rowptr;
+    c->d_col = t_col;
+    c->d_val = t_val;
+    t_rowptr = nullptr;
+    t_col = nullptr;
+    t_val = nullptr;
   } else {
-    uint64_t *t_rowptr = nullptr;
-    uint32_t *t_col = nullptr;
-    float *t_val = nullptr;
-    UP_CHECK(hipMalloc(&t_rowptr, sizeof(uint64_t) * (nrows + 1)));
-    UP_CHECK(hipMalloc(&t_col, sizeof(uint32_t) * std::max<uint64_t>(nnz, 1)));
-    if (keep_val) UP_CHECK(hipMalloc(&t_val, sizeof(float) * std::max<uint64_t>(nnz, 1)));
-    UP_CHECK(hipMemcpyAsync(t_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (nnz) UP_CHECK(hipMemcpyAsync(t_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
-    if (keep_val && nnz) UP_CHECK(hipMemcpyAsync(t_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    UP_CHECK(hipMalloc(&c->d_rowptr, sizeof(uint64_t) * (nrows + 1)));
+    UP_CHECK(hipMalloc(&c->d_col, sizeof(uint32_t) * (c->nnz + 8)));
+    if (keep_val) UP_CHECK(hipMalloc(&c->d_val, sizeof(float) * (c->nnz + 8)));
     if (nrows) {
       const int grid = grid_for(nrows * 16, 256, ctx->cu_count * 8);
       hipLaunchKernelGGL(k_translate, dim3(grid), dim3(256), 0, ctx->stream, t_rowptr, t_col, t_val,
@@ -1418,17 +1477,19 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
     } else {
       UP_CHECK(hipMemsetAsync(c->d_rowptr, 0, sizeof(uint64_t), ctx->stream));
     }
-    hipError_t e1 = hipGetLastError();
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    UP_CHECK(hipGetLastError());
+    UP_CHECK(hipStreamSynchronize(ctx->stream));
     hipFree(t_rowptr);
     hipFree(t_col);
     if (t_val) hipFree(t_val);
-    UP_CHECK(e1);
-    UP_CHECK(e2);
+    t_rowptr = nullptr;
+    t_col = nullptr;
+    t_val = nullptr;
   }
+  hipFree(d_flags);
+  d_flags = nullptr;
 #undef UP_CHECK
   pick_lpr(c);
-  (void)rc;
   *out = c;
   return ADMM_OK;
 }

@@ -791,3 +791,32 @@ def test_tied_ranks_are_the_reference_sort(ctx, oracle):
         ctx.tied_ranks(ctx.vec(n, x), ranks)
         np.testing.assert_array_equal(ranks.download(), oracle.tied_rank(x))
     np.testing.assert_array_equal(oracle.tied_rank(np.array([3, 1, 3, 2], np.float32)), [3.5, 1.0, 3.5, 2.0])
+
+
+def test_upload_checks_on_the_device(ctx, oracle):
+    """what admm_csr_upload validates: a row pointer that decreases, an index beyond dim, and (accepted, but
+    noted: such sets run the element-by-element FTRL kernel) a row that stores a column twice -- the
+    reference applies its update twice then, in sequence (src/ftrl.cc:80-87)"""
+    from admm_amd import capi
+    lab = np.array([1, 0, 1], np.float32)
+    with pytest.raises(capi.AdmmError, match="rowptr decreases at row 1"):
+        ctx.csr_upload(np.array([0, 2, 1, 3], np.uint64), np.array([1, 2, 3], np.uint32), None, lab, dim=10, add_bias=True)
+    with pytest.raises(capi.AdmmError, match="feature index 9 of row 2"):
+        ctx.csr_upload(np.array([0, 1, 2, 3], np.uint64), np.array([1, 2, 9], np.uint32), None, lab, dim=10, add_bias=True)
+    # unsorted rows without a repeated column are ordinary sets; with one, the exact pass still matches
+    dim = 12
+    rowptr = np.array([0, 3, 6, 8], np.uint64)
+    col = np.array([4, 1, 4, 7, 2, 5, 3, 3], np.uint32)          # rows 0 and 2 repeat a column
+    val = np.array([1, 1, 1, 1, 1, 1, 0.5, 2.0], np.float32)
+    raw = oracle.Csr(rowptr, col, val, lab, dim)
+    tr = oracle.translate(raw)
+    dev = ctx.csr_upload(rowptr, col, val, lab, dim, add_bias=True)
+    w, z, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    zero = ctx.vec(dim)
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    for _ in range(3):
+        dev.ftrl_pass(w, z, n, zero, zero, 0.1, 1.0, 0.01, 0.1)
+        oracle.ftrl_run(tr, hw, hz, hn, np.zeros(dim, np.float32), np.zeros(dim, np.float32), 0.1, 1.0, 0.01, 0.1)
+    for got, ref in ((w, hw), (z, hz), (n, hn)):
+        close(got.download(), ref, rtol=1e-5, atol=1e-7)
+    dev.destroy()
