@@ -173,6 +173,7 @@ class SampleSet {
 
  protected:
   void Release();
+  void EnsureHost();  // the row cursor's host arrays, fetched back from the device when first needed
   admm_csr *csr_ = nullptr;
   std::vector<uint64_t> rowptr_;
   std::vector<uint32_t> col_;

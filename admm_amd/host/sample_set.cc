@@ -289,7 +289,37 @@ bool SampleSet::Initialize(const std::string &uri, uint32_t part_index, uint32_t
     std::fprintf(stderr, "%s\n", admm_last_error());
     std::abort();
   }
+  // The parsed arrays live in HBM from here on; the host copies (12 bytes per entry, 80 GB for a 10^10-entry
+  // shard) are given back.  The row cursor fetches them from the device again if anybody uses it.
+  std::vector<uint64_t>().swap(rowptr_);
+  std::vector<uint32_t>().swap(col_);
+  std::vector<float>().swap(val_);
+  std::vector<float>().swap(label_);
+  std::vector<size_t>().swap(col_wide_);
   return true;
+}
+
+void SampleSet::EnsureHost() {
+  if (!rowptr_.empty() || csr_ == nullptr) return;
+  uint64_t nr = 0, nz = 0, dm = 0;
+  ADMM_CALL(admm_csr_shape(csr_, &nr, &nz, &dm));
+  std::vector<uint64_t> rp(nr + 1);
+  std::vector<uint32_t> c(nz);
+  std::vector<float> v(nz);
+  label_.resize(nr);
+  ADMM_CALL(admm_csr_download(csr_, rp.data(), c.data(), v.data(), label_.data()));
+  // the device holds translated rows (bias column first, indices shifted by one): undo that
+  rowptr_.resize(nr + 1);
+  col_.resize(nz - nr);
+  val_.resize(nz - nr);
+  for (uint64_t r = 0; r < nr; ++r) {
+    rowptr_[r] = rp[r] - r;
+    for (uint64_t k = rp[r] + 1; k < rp[r + 1]; ++k) {
+      col_[k - r - 1] = c[k] - 1;
+      val_[k - r - 1] = v[k];
+    }
+  }
+  rowptr_[nr] = rp[nr] - nr;
 }
 
 void SampleSet::PrepareTransposed(uint64_t panel_rows, uint32_t col_block, bool relabel) {
@@ -313,6 +343,7 @@ bool SampleSet::Next() {
 
 Row SampleSet::GetData() {
   Row r;
+  EnsureHost();
   const uint64_t b = rowptr_[current_index_], e = rowptr_[current_index_ + 1];
   if (col_wide_.size() != col_.size()) col_wide_.assign(col_.begin(), col_.end());
   r.label = label_[current_index_];

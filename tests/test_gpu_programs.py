@@ -282,3 +282,21 @@ def test_launcher_restarts_on_254_and_reports_failures(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "tools", "dmlc_local.py"), "-n", "2", str(bad)],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 3
+
+
+def test_row_cursor_reads_the_rows_back_from_the_device(tmp_path):
+    """SampleSet keeps no host copy of a loaded part; Next / GetData (src/sample_set.cc:32-68) fetch the rows
+    from HBM again: parsecheck -c prints them through the cursor, and they are the file's rows"""
+    import subprocess
+    raw = make_synth_csr(300, 500, 7, seed=11, binary=False)
+    path = str(tmp_path / "part-00000")
+    write_libsvm(path, raw)
+    exe = os.path.join(ROOT, "admm_amd", "bin", "parsecheck")
+    out = {}
+    for flag in ("-c", "-d"):
+        p = subprocess.run([exe, path, "0", "1", flag], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-1000:]
+        out[flag] = p.stdout.splitlines()
+    assert out["-c"][0].split() == [str(raw.nrows), str(len(raw.col) + raw.nrows)]   # Size(), nnz with the bias column
+    assert out["-c"][1:] == out["-d"][1:]       # the same rows as the plain dump of the parsed text
+    assert len(out["-c"]) == raw.nrows + 1
