@@ -234,7 +234,7 @@ bool SampleSet::ParseText(const std::string &uri, uint32_t part_index, uint32_t 
     col_.resize(nnz);
     val_.resize(nnz);
     auto stitch = [&](int t) {
-      const Chunk &c = chunks[t];
+      Chunk &c = chunks[t];
       if (!c.label.empty()) std::memcpy(label_.data() + row0[t], c.label.data(), sizeof(float) * c.label.size());
       if (!c.col.empty()) {
         std::memcpy(col_.data() + nnz0[t], c.col.data(), sizeof(uint32_t) * c.col.size());
@@ -245,6 +245,7 @@ bool SampleSet::ParseText(const std::string &uri, uint32_t part_index, uint32_t 
         rowptr_[row0[t] + r] = at;
         at += c.rowlen[r];
       }
+      c = Chunk();  // the run's own arrays are not needed any more
     };
     pool.clear();
     for (int t = 1; t < nthr; ++t) pool.emplace_back(stitch, t);
