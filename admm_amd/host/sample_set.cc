@@ -325,8 +325,9 @@ void SampleSet::EnsureHost() {
 
 void SampleSet::PrepareTransposed(uint64_t panel_rows, uint32_t col_block, bool relabel) {
   ADMM_CHECK(csr_ != nullptr);
-  ADMM_CALL(admm_csr_build_transposed(csr_, panel_rows, col_block));
+  // relabelling first: the copies are then built once, in the final numbering
   if (relabel) ADMM_CALL(admm_csr_relabel_by_frequency(csr_));
+  ADMM_CALL(admm_csr_build_transposed(csr_, panel_rows, col_block));
 }
 
 // Row cursor over the single in-memory block (src/sample_set.cc:32-68)
