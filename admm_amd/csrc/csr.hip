@@ -878,7 +878,7 @@ int build_column_stream(admm_csr *csr, bool want) {
   csr->tc_words = words;
   csr->tc_entries = entries;
   csr->has_tc = true;
-  if (getenv("ADMM_VERBOSE"))
+  if (const char *vb = getenv("ADMM_VERBOSE"); vb && vb[0] != '0')
     fprintf(stderr, "[admm_hip] column stream: %llu words for %llu entries (ids < %u)\n", (unsigned long long)words,
             (unsigned long long)entries, ncols);
   return ADMM_OK;
@@ -1276,7 +1276,7 @@ int build_forward_panels(admm_csr *csr) {
   csr->fp_nnz = total;
   csr->hp_words = hwords;
   csr->has_fp = true;
-  if (getenv("ADMM_VERBOSE"))
+  if (const char *vb = getenv("ADMM_VERBOSE"); vb && vb[0] != '0')
     fprintf(stderr, "[admm_hip] forward panels: %llu rows, hot stream %llu words (ids < %u), %llu entries outside it\n",
             (unsigned long long)csr->nrows, (unsigned long long)hwords, nhot, (unsigned long long)total);
   return ADMM_OK;
