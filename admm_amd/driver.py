@@ -368,6 +368,40 @@ def global_test_metrics(ctx, test_set, groups):
     return (ltotal / total if total else 0.0), auc, total
 
 
+def ftrl_exact_vs_minibatch(ctx, rows, dim, mean_nnz, seed, prm, batches=(4096, 65536), test_rows=0, col_block=2048,
+                            **synth_kw):
+    """One FTRL pass (src/ftrl.cc:101-145) over the same generated rows in the reference's row-by-row form and in
+    the mini-batch form for each size in `batches`, each from zero state; test logloss / AUC of every resulting
+    model on one generated test set.  prm = (alpha, beta, l_1, l_2).  Returns {"exact": {...}, "batch": {size:
+    {..., "dlogloss", "dauc"}}}: how much of the model's quality the batched semantics cost."""
+    test = ctx.csr_synth(test_rows or max(1, rows // 20), dim, mean_nnz, seed=seed + 1, **synth_kw)
+    off, reg = ctx.vec(dim), ctx.vec(dim)
+
+    def one(batch):
+        train = ctx.csr_synth(rows, dim, mean_nnz, seed=seed, **synth_kw)
+        if batch > 1:
+            train.relabel_by_frequency()
+            train.build_transposed(panel_rows=batch, col_block=col_block)
+        w, z, n = (ctx.vec(dim) for _ in range(3))
+        train.ftrl_pass(w, z, n, off, reg, *prm, batch=batch)
+        ll, auc, nr = test.metrics([w])
+        train.destroy()
+        for v in (w, z, n):
+            v.free()
+        return {"test_logloss": ll, "test_auc": auc}
+
+    out = {"rows": rows, "test_rows": test.nrows, "exact": one(1), "batch": {}}
+    for b in batches:
+        rec = one(int(b))
+        rec["dlogloss"] = rec["test_logloss"] - out["exact"]["test_logloss"]
+        rec["dauc"] = rec["test_auc"] - out["exact"]["test_auc"]
+        out["batch"][int(b)] = rec
+    test.destroy()
+    off.free()
+    reg.free()
+    return out
+
+
 def format_line(psid, loss, auc, n):
     """the per-iteration report of src/admm_allreduce.cpp:79"""
     return "%s | %.7f | %.7f | %d" % (psid, loss, auc, n)

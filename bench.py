@@ -68,21 +68,40 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-linesearch", action="store_true",
                     help="skip the two extra iterations that time the other line search mode")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="c3 on one GPU also runs the ftrl configuration and a c5 shard at full size after its "
+                         "timed region and attaches them as config.other_configs; this switch skips that")
     ap.add_argument("--seed", type=int, default=20251111)
     ap.add_argument("--explicit-values", action="store_true",
                     help="store the generated values (all 1.0) as an f32 array instead of keeping the set as "
                          "a pattern matrix, which is how the library keeps any all-ones sample set")
-    ap.add_argument("--allreduce", choices=["lib", "torch"], default="lib",
+    ap.add_argument("--allreduce", choices=["lib", "torch"], default=None,
                     help="lib: admm_allreduce_sum_f32 (RCCL through the library, the product's path); "
-                         "torch: torch.distributed's all-reduce on the same buffer")
+                         "torch: torch.distributed's all-reduce on the same buffer.  Not given: lib, and when the "
+                         "library's communicator fails or gives no answer the run goes on with torch's and says so "
+                         "in config.allreduce_fallback; given as lib, such a failure ends the run with exit code 3")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    args.rows = args.rows or cfg["rows"]
-    args.dim = args.dim or cfg["dim"]
-    args.mean_nnz = args.mean_nnz or cfg["draws"]
-    args.col_block = args.col_block or cfg["col_block"]
-    args.heavy, args.per_rank = cfg["heavy"], cfg["per_rank"]
-    return args
+    args.overridden = bool(args.rows or args.dim or args.mean_nnz or args.panel_rows or args.col_block)
+    return apply_config(args, args.config)
+
+
+def apply_config(args, name, **override):
+    """a copy of `args` set up for configuration `name` (explicit --rows etc. survive for the named one only)"""
+    import copy
+    a = copy.copy(args)
+    cfg = CONFIGS[name]
+    primary = name == args.config
+    a.config = name
+    a.rows = (args.rows if primary else 0) or cfg["rows"]
+    a.dim = (args.dim if primary else 0) or cfg["dim"]
+    a.mean_nnz = (args.mean_nnz if primary else 0.0) or cfg["draws"]
+    a.col_block = (args.col_block if primary else 0) or cfg["col_block"]
+    if not primary:
+        a.panel_rows = 0
+    a.heavy, a.per_rank = cfg["heavy"], cfg["per_rank"]
+    for k, v in override.items():
+        setattr(a, k, v)
+    return a
 
 
 def synth_kw(args):
@@ -215,6 +234,10 @@ class Job:
         self.ctx = capi.Context(self.local_rank)
         self.allreduce_path = "single rank"
         self.comm_stuck = False
+        self.allreduce_fallback = None
+        lib_demanded = args.allreduce == "lib"
+        if args.allreduce is None:
+            args.allreduce = "lib"
         if self.share_gpu:
             self.ctx.rank, self.ctx.world = self.rank, self.world
             self.ctx.exchange = self._host_exchange
@@ -241,13 +264,21 @@ class Job:
                 th.start()
                 th.join(timeout=float(os.environ.get("ADMM_BENCH_COMM_TIMEOUT", "120")))
                 if not state.get("ok"):
-                    why = state.get("error", "no answer in time")
+                    why = state.get("error", "no answer within %s s" % os.environ.get("ADMM_BENCH_COMM_TIMEOUT", "120"))
+                    self.allreduce_fallback = "rank %d: %s" % (self.rank, why)
                     sys.stderr.write("rank %d: library communicator failed (%s); using torch.distributed\n" % (self.rank, why))
                     args.allreduce = "torch"
                     self.comm_stuck = th.is_alive()
             ok = self.host_sum([1.0 if args.allreduce == "lib" else 0.0])[0]
             if ok != self.world:        # every rank takes the same path
+                if self.allreduce_fallback is None and args.allreduce == "lib":
+                    self.allreduce_fallback = "the library communicator failed on %d other rank(s)" % int(self.world - ok)
                 args.allreduce = "torch"
+                if lib_demanded:
+                    sys.stderr.write("rank %d: --allreduce lib was asked for and the library's communicator is not usable "
+                                     "(%s)\n" % (self.rank, self.allreduce_fallback))
+                    sys.stderr.flush()
+                    os._exit(3)
             if args.allreduce == "torch":
                 self.allreduce_path = "torch.distributed all_reduce (nccl = RCCL)"
         self.use_lib = args.allreduce == "lib" or self.world == 1
@@ -291,9 +322,10 @@ class Job:
         self.adist.finalize()
 
 
-def pmc_traffic(args, world, rows_total, sym):
-    """HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE of this same
-    command, corrected as the file explains); only for the workload they were taken on"""
+def pmc_traffic(args, world, rows_total):
+    """HBM bytes per launch of the two sweeps from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE
+    of this same command, corrected as the file explains); only for the workload they were taken on.
+    Returns ({"forward_csr_sweep": bytes, "transposed_block_sweep": bytes}, source) or (None, None)."""
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
     if not os.path.exists(tfile):
         return None, None
@@ -302,12 +334,15 @@ def pmc_traffic(args, world, rows_total, sym):
     if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus"), bool(wl.get("explicit_values"))) != \
             (rows_total, args.dim, world, args.explicit_values):
         return None, None
-    if sym == "k_transposed<false" and "transposed_sweep_total" in pmc:   # cells + column stream: one sweep
-        return pmc["transposed_sweep_total"]["traffic_bytes"], "profiles/pmc_traffic_%s.json" % args.config
+    got = {}
     for name, rec in pmc["kernels"].items():
-        if sym in name:
-            return rec["traffic_bytes"], "profiles/pmc_traffic_%s.json" % args.config
-    return None, None
+        if "k_forward_rp<1" in name:
+            got["forward_csr_sweep"] = rec["traffic_bytes"]
+        elif "k_transposed<false" in name and "transposed_sweep_total" not in pmc:
+            got["transposed_block_sweep"] = rec["traffic_bytes"]
+    if "transposed_sweep_total" in pmc:   # cells + column stream: one sweep
+        got["transposed_block_sweep"] = pmc["transposed_sweep_total"]["traffic_bytes"]
+    return (got or None), "profiles/pmc_traffic_%s.json" % args.config
 
 
 def sweep_kernels(train, rows, dim, fwd_ms, fwd_n, tr_ms, tr_n, margins_written=True):
@@ -333,16 +368,29 @@ def sweep_kernels(train, rows, dim, fwd_ms, fwd_n, tr_ms, tr_n, margins_written=
 
 
 def roofline_of(kernels, dom, traffic, traffic_src):
+    """roofline record of the dominant sweep `dom`.  traffic: {kernel: PMC bytes per launch} or None; with it every
+    kernel also gets frac_counters = PMC bytes / its HIP-event time / peak, the share of the HBM peak that the
+    bytes the kernel really moved amount to (frac divides the problem's 8 bytes per stored entry instead)."""
+    for name, k in kernels.items():
+        t = (traffic or {}).get(name)
+        k["traffic_bytes"] = t
+        k["frac"] = k["achieved_GBs"] / HBM_PEAK_GBS if k["achieved_GBs"] else None
+        k["frac_stored"] = k["stored_GBs"] / HBM_PEAK_GBS if k["stored_GBs"] else None
+        k["frac_counters"] = (t / (k["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (t and k["avg_ms"] > 0) else None
     k = kernels[dom]
     return {"bound": "hbm", "kernel": dom, "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": k["achieved_GBs"] / HBM_PEAK_GBS,
+            "frac": k["frac"],
             "algorithmic_bytes": k["algorithmic_bytes"],
-            "stored_bytes": k["stored_bytes"], "frac_stored": k["stored_GBs"] / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "stored_bytes": k["stored_bytes"], "frac_stored": k["frac_stored"],
+            "traffic": k["traffic_bytes"], "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "frac_counters": k["frac_counters"],
             "traffic_measured_in_run": False,
             "note": "achieved/frac divide the ALGORITHMIC bytes (8 B per stored entry) by the kernel's HIP-event time; "
                     "stored_bytes/frac_stored divide what the kernel's layout actually holds; traffic is a PMC "
-                    "measurement of an earlier run of this command kept under profiles/, not of this run",
+                    "measurement of an earlier run of this command kept under profiles/, not of this run, and "
+                    "frac_counters = traffic / this run's kernel time / peak: the kernels move fewer bytes than the "
+                    "8 per entry the metric counts (pattern matrix, row masks, 16-bit stream words), so frac says how "
+                    "close the sweep is to the metric's roofline and frac_counters how busy the HBM really is",
             "kernels": kernels}
 
 
@@ -350,8 +398,9 @@ def roofline_of(kernels, dom, traffic, traffic_src):
 # ADMM iteration (c3, c5)
 # ---------------------------------------------------------------------------------------------------
 
-def run_admm(args):
-    job = Job(args)
+def run_admm(args, job, side=False):
+    """the ADMM iteration benchmark; returns rank 0's record (None on the other ranks).  side: the configuration
+    is run beside the primary one (no CPU baseline, no other line search modes)."""
     ctx, capi, rank, world = job.ctx, job.capi, job.rank, job.world
     from admm_amd import driver
     from admm_amd import dist as adist
@@ -429,7 +478,8 @@ def run_admm(args):
     # untimed iteration each), so that the line shows what an ADMM iteration costs in the library's default
     # mode and in the fastest one as well.  Not part of `value`.
     other = None
-    if not args.no_other_linesearch:
+    out = None
+    if not args.no_other_linesearch and not side:
         names = ("from margins", "by full sweeps", "from margins, accepted point too")
         other = []
         for mode in (0, 1, 2):
@@ -466,8 +516,8 @@ def run_admm(args):
         rows = r1 - r0
         kernels = sweep_kernels(train, rows, args.dim, fwd_ms, fwd_n, tr_ms, tr_n)
         dom = "transposed_block_sweep" if tr_ms >= fwd_ms else "forward_csr_sweep"
-        traffic, traffic_src = pmc_traffic(args, world, rows_total,
-                                           "k_transposed<false" if dom == "transposed_block_sweep" else "k_forward_rp<1")
+        traffic, traffic_src = pmc_traffic(args, world, rows_total)
+        sweep_ms = (fwd_ms + tr_ms) / max(args.steps, 1)
         out = {
             "metric": METRIC,
             "value": swept / dt,
@@ -491,6 +541,7 @@ def run_admm(args):
                 "values": "all 1.0, stored as f32" if args.explicit_values else
                           "all 1.0, implicit (pattern matrix: no value arrays in HBM)",
                 "allreduce": job.allreduce_path,
+                "allreduce_fallback": job.allreduce_fallback,
                 "sharding": "contiguous row ranges of equal size; synthetic rows are identically distributed, so the "
                             "shards' entry counts differ by the factor below",
                 "shard_nnz_max_over_mean": nnz_max / (nnz_total / world),
@@ -498,6 +549,7 @@ def run_admm(args):
                 "objective_evals_total": evals_total,
                 "forward_sweeps_total": fwd_total, "transposed_sweeps_total": tr_total,
                 "admm_iterations_per_s": args.steps / dt,
+                "ms_per_step_outside_the_sweeps": dt / args.steps * 1e3 - sweep_ms,
                 "other_line_search": other,
                 "global_test_metrics": {"logloss": g_loss, "auc": g_auc, "rows": g_rows},
                 "generate_and_build_s": t_gen,
@@ -509,22 +561,26 @@ def run_admm(args):
             },
             "roofline": roofline_of(kernels, dom, traffic, traffic_src),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not side:
             out["cpu_baseline"] = cpu_baseline(ctx, args, float(prm.step_size))
-        print(json.dumps(out), flush=True)
 
     train.destroy()
     test.destroy()
-    job.close()
+    for v in (zg, worker.base_vec_, worker.bias_vec_, worker.langr_vec_, worker.nt_vec_, worker.zt_vec_,
+              worker._n, worker._z):
+        v.free()
+    if job.use_lib:
+        payload.free()
+    return out if rank == 0 else None
 
 
 # ---------------------------------------------------------------------------------------------------
 # FTRL single pass
 # ---------------------------------------------------------------------------------------------------
 
-def run_ftrl(args):
-    job = Job(args)
+def run_ftrl(args, job, side=False):
     ctx, capi, rank, world = job.ctx, job.capi, job.rank, job.world
+    out = None
     from admm_amd import dist as adist
     rows_total = args.rows
     r0, r1 = adist.shard_range(rows_total, rank, world)       # N > 1: independent passes over row shards
@@ -601,6 +657,10 @@ def run_ftrl(args):
         for grp in st:
             for v in grp:
                 v.free()
+        # what the batched semantics cost in model quality: the same 1M rows, one pass each way
+        from admm_amd import driver
+        exact["quality"] = driver.ftrl_exact_vs_minibatch(ctx, 1_000_000, dim, args.mean_nnz, args.seed, prm,
+                                                          batches=(4096, batch), col_block=args.col_block, **synth_kw(args))
 
     if rank == 0:
         rows = r1 - r0
@@ -641,20 +701,59 @@ def run_ftrl(args):
                                  "wall time of one pass between two stream synchronisations (kernel_ms_per_pass: HIP events "
                                  "around every kernel of one extra pass)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not side:
             out["cpu_baseline"] = cpu_baseline(ctx, args, 0.01)
-        print(json.dumps(out), flush=True)
     train.destroy()
     test.destroy()
-    job.close()
+    for v in (w, z, n, off, reg):
+        v.free()
+    return out
+
+
+def summary_of(rec):
+    """what config.other_configs keeps of a configuration run beside the primary one"""
+    rf = rec["roofline"]
+    keep = {"name": rec["config"]["name"], "workload": rec["config"]["workload"], "steps": rec["steps"],
+            "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit": rec["unit"],
+            "scaling": rec["scaling"],
+            "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "frac", "frac_stored", "traffic", "frac_counters",
+                                                "traffic_source", "algorithmic_bytes", "stored_bytes")}}
+    if "kernels" in rf:
+        keep["roofline"]["kernels"] = {
+            n: {k: v.get(k) for k in ("avg_ms", "launches", "frac", "frac_stored", "frac_counters", "traffic_bytes")}
+            for n, v in rf["kernels"].items()}
+    for k in ("admm_iterations_per_s", "ms_per_step_outside_the_sweeps", "global_test_metrics", "mode", "batches_per_pass",
+              "test_logloss_after_one_pass", "test_auc_after_one_pass", "row_by_row_pass", "exact_vs_minibatch",
+              "kernel_ms_per_pass", "generate_and_build_s", "rank0_hbm_bytes", "shard_nnz_max_over_mean"):
+        if k in rec["config"]:
+            keep[k] = rec["config"][k]
+    return keep
 
 
 def main():
     args = parse_args()
-    if args.config == "ftrl":
-        run_ftrl(args)
-    else:
-        run_admm(args)
+    job = Job(args)
+    run = run_ftrl if args.config == "ftrl" else run_admm
+    out = run(args, job)
+    # One GPU, default workload: the other two single-GPU configurations run in this same process after the
+    # timed region, at full size, and ride along in the line (the c3 record stays the headline).
+    if job.world == 1 and args.config == "c3" and not args.overridden and not args.explicit_values \
+            and not args.no_other_configs:
+        others = []
+        for name, kw in (("ftrl", dict(steps=20, warmup=3)), ("c5", dict(steps=3, warmup=1))):
+            t0 = time.perf_counter()
+            try:
+                a = apply_config(args, name, no_cpu_baseline=True, no_other_linesearch=True, **kw)
+                rec = (run_ftrl if name == "ftrl" else run_admm)(a, job, side=True)
+                rec = summary_of(rec)
+            except Exception as e:   # noqa: BLE001 - a side configuration must not take the headline down with it
+                rec = {"name": name, "error": "%s: %s" % (type(e).__name__, e)}
+            rec["wall_s"] = time.perf_counter() - t0
+            others.append(rec)
+        out["config"]["other_configs"] = others
+    if job.rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    job.close()
 
 
 if __name__ == "__main__":
