@@ -11,7 +11,7 @@ HOST = os.path.join(PKG, "host")
 OBJ = os.path.join(PKG, "csrc", "_obj")
 LIB = os.path.join(PKG, "libadmm_hip.so")
 
-HIP_SOURCES = ["ctx.hip", "csr.hip", "sweep.hip", "ftrl.hip", "auc.hip", "comm.hip"]
+HIP_SOURCES = ["ctx.hip", "csr.hip", "sweep.hip", "ftrl_batch.hip", "ftrl.hip", "auc.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off",
              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
@@ -27,7 +27,7 @@ def _newer(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "internal.h"),
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "sweep_common.h"),
             os.path.join(ROOT, "include", "admm_hip.h")]
     if _newer(obj, deps):
         subprocess.check_call([HIPCC] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])

@@ -130,7 +130,16 @@ int wait_scalars(admm_ctx *ctx) {
 #endif
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  return ADMM_OK;
+  return check_device_reports(ctx);
+}
+
+int check_device_reports(admm_ctx *ctx) {
+  volatile unsigned long long *word = ctx->h_seq + 1;
+  if (*word == 0) return ADMM_OK;
+  *word = 0;
+  set_error("admm_ftrl_pass: the one-launch mini-batch pass gave up at a device-wide barrier (a workgroup was not "
+            "resident or never arrived); its results are invalid -- ADMM_FTRL_PERSISTENT=0 selects the per-batch launches");
+  return ADMM_ERR_STATE;
 }
 
 int finish_partials(admm_ctx *ctx, int nscalars, int nblocks) {
@@ -451,6 +460,7 @@ extern "C" int admm_ctx_destroy(admm_ctx *ctx) {
   if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
   if (ctx->lbfgs_ws) hipFree(ctx->lbfgs_ws);
   if (ctx->d_multi) hipFree(ctx->d_multi);
+  if (ctx->d_ps) hipFree(ctx->d_ps);
   if (ctx->auc_ws) hipFree(ctx->auc_ws);
   if (ctx->row_ws) hipFree(ctx->row_ws);
   if (ctx->d_lb) hipFree(ctx->d_lb);
@@ -462,7 +472,7 @@ extern "C" int admm_ctx_destroy(admm_ctx *ctx) {
 extern "C" int admm_sync(admm_ctx *ctx) {
   ADMM_REQUIRE(ctx, "admm_sync: ctx is NULL");
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  return ADMM_OK;
+  return check_device_reports(ctx);
 }
 
 extern "C" int admm_timing_enable(admm_ctx *ctx, int on) {
@@ -544,7 +554,7 @@ extern "C" int admm_vec_download(admm_ctx *ctx, float *dst_host, const float *sr
   ADMM_REQUIRE(ctx && dst_host && src, "admm_vec_download: bad arguments");
   ADMM_HIP_CHECK(hipMemcpyAsync(dst_host, src, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  return ADMM_OK;
+  return check_device_reports(ctx);
 }
 
 // ---- consensus algebra ------------------------------------------------------------------------

@@ -97,6 +97,9 @@ struct admm_ctx {
   // argument table of a multi-pass FTRL launch
   void *d_multi = nullptr;
   size_t multi_bytes = 0;
+  // barrier words and running maxima of the one-launch mini-batch FTRL pass
+  void *d_ps = nullptr;
+  size_t ps_bytes = 0;
   // RCCL
   void *comm = nullptr;
   int rank = 0, world = 1;
@@ -222,12 +225,19 @@ int finish_partials(admm_ctx *ctx, int nscalars, int nblocks);
 // results of everything queued
 int reduce_rows_queue(admm_ctx *ctx, int first, int count, int split, int nblocks_a, int nblocks_b);
 int wait_scalars(admm_ctx *ctx);
+// After a wait for the stream: has a kernel reported through the pinned block that it gave up (the one-launch
+// mini-batch FTRL pass at a device-wide barrier)?  The report is sticky until it has been returned once.
+int check_device_reports(admm_ctx *ctx);
 
 int ensure_rowbuf(admm_csr *csr);
 int build_forward_panels(admm_csr *csr);  // csr.hip
 int build_dep(admm_csr *csr);             // csr.hip: previous-occurrence table of the sequential FTRL pass
 int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool column_stream);  // csr.hip
 int ensure_taccum(admm_csr *csr);
+// mini-batch FTRL pass in one launch (ftrl_batch.hip)
+bool ftrl_persistent_eligible(const admm_csr *csr, uint64_t batch);
+int ftrl_pass_persistent(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,
+                         float alpha, float beta, float l1, float l2, const float *folded_max);
 
 // sweeps (sweep.hip)
 enum FwdMode { FWD_EVAL = 0, FWD_LBFGS = 1, FWD_FTRL = 2, FWD_MARGIN = 3 };

@@ -4,6 +4,7 @@
 // plus prediction / logloss, the batch objective f,g, the L-BFGS driver and the mini-batch FTRL
 // pass.
 #include "internal.h"
+#include "sweep_common.h"
 
 #include <algorithm>
 #include <cmath>
@@ -40,14 +41,6 @@ struct FwdArgs {
   float scale;
 };
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kMaskSlots = 16;  // copies of the mask columns' global sums in the mini-batch FTRL pass (see RpArgs::mpart)
-
-__device__ inline float clamp35(float m) { return fmaxf(fminf(m, 35.0f), -35.0f); }
 
 // Forward sweep geometry: one workgroup per CU, split into kFwConsumers reducing threads and
 // kFwProducers streaming threads; a tile is up to kFwRowSlots consecutive rows (the launch picks
@@ -615,24 +608,6 @@ __global__ void __launch_bounds__(fw_threads(HASVAL)) k_forward(FwdArgs a) {
 
 constexpr int kRpThreads = kHpLanes;
 
-__device__ inline unsigned long long rp_to_fx(float x, float scale) { return (unsigned long long)(long long)(x * scale); }
-
-// sum of a 64-bit value over the 16 lanes of a DPP row (row_ror by 8, 4, 2, 1); every lane gets the total
-__device__ inline long long row16_sum(long long x) {
-#define ROW16_STEP(CTRL)                                                                                      \
-  {                                                                                                           \
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)x, CTRL, 0xF, 0xF, false);     \
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)x >> 32), CTRL, 0xF, 0xF, false); \
-    x += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);                                \
-  }
-  ROW16_STEP(0x128)
-  ROW16_STEP(0x124)
-  ROW16_STEP(0x122)
-  ROW16_STEP(0x121)
-#undef ROW16_STEP
-  return x;
-}
-
 // mini-batch FTRL: a batch is one short panel per workgroup, and a few hundred workgroups adding to the
 // same kMaskCols global words at once take turns (9 of the kernel's 32 microseconds); they are spread
 // over kMaskSlots copies of those words, which the per-coordinate pass adds up and clears
@@ -666,12 +641,6 @@ struct RpArgs {
   float gscale;
   uint64_t panel0, pcount; // panels [panel0, panel0 + pcount) are swept by this launch
 };
-
-// An integer-valued double of magnitude below 2^51 as a 64-bit integer: adding 1.5 * 2^52 leaves the
-// integer (offset by 2^51) in the low mantissa bits.
-__device__ inline unsigned long long rp_d2fx(double s) {
-  return (unsigned long long)(__double_as_longlong(s + 6755399441055744.0) - 0x4338000000000000ll);
-}
 
 #ifndef ADMM_RP_PRELIST
 #define ADMM_RP_PRELIST (MODE == FWD_FTRL)
@@ -1132,10 +1101,6 @@ __global__ void __launch_bounds__(256) k_wsum(const float *__restrict__ w0, cons
 }
 
 // whole-set sweep over the row-panel copy
-// grid of the kernels that fill csr->d_wsum and leave max |wsum| per workgroup behind
-static inline int wsum_grid(admm_ctx *ctx, uint64_t dim) { return grid_for(dim, 256, std::min(ctx->cu_count * 8, kMaxPartialBlocks)); }
-static inline float *wsum_blockmax(admm_ctx *ctx) { return reinterpret_cast<float *>(ctx->d_partials + 6 * (size_t)kMaxPartialBlocks); }
-
 // v[n - 1] <- max of v[0 .. n)
 __global__ void __launch_bounds__(256) k_max_fold(float *v, int n) {
   __shared__ float sh[4];
@@ -1363,20 +1328,6 @@ struct TArgs {
   uint64_t fdim;
 };
 
-
-typedef unsigned long long fx_t;  // two's-complement fixed point held in an unsigned word
-
-__device__ inline float ftrl_weight(float z, float n, float c, float alpha, float beta, float l1, float l2) {
-  // src/ftrl.cc:61-66 (threshold on l1, shrink by the literal 1)
-  const float sign = z < 0.0f ? -1.0f : 1.0f;
-  if (sign * z <= l1) return 0.0f;
-  const float num = sign * 1 - z + l2 * c;
-  const double den = ((double)beta + sqrt((double)n)) / (double)alpha + (double)l2;
-  return (float)((double)num / den);
-}
-
-
-__device__ inline fx_t to_fx(float x, float scale) { return (fx_t)(long long)(x * scale); }
 
 // Integer LDS atomics run three times as fast as float ones on gfx950 and make the sum
 // independent of the order of the adds.
@@ -2318,6 +2269,16 @@ int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *
     ADMM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, ctx->stream, blockmax, wgrid);
     ADMM_HIP_CHECK(hipGetLastError());
+  }
+  if (ftrl_persistent_eligible(csr, batch) && csr->d_mpart) {
+    // the whole pass in one launch (ftrl_batch.hip); same results bit for bit
+    ADMM_TRY(ftrl_pass_persistent(csr, w, z, n, offset, reg_offset, alpha, beta, l1, l2, blockmax + wgrid - 1));
+    if (csr->nrows) {
+      hipLaunchKernelGGL(k_ftrl_last_row, dim3(1), dim3(64), 0, ctx->stream, csr->d_rowptr, csr->d_col,
+                         csr->d_perm, csr->nrows - 1, z, n, reg_offset, alpha, beta, l1, l2, w);
+      ADMM_HIP_CHECK(hipGetLastError());
+    }
+    return ADMM_OK;
   }
   TArgs fuse{};
   fuse.fw = w;
