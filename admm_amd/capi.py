@@ -19,7 +19,7 @@ SYMBOLS = [
     "admm_vec_alloc", "admm_vec_free", "admm_vec_zero", "admm_vec_copy", "admm_vec_upload",
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
-    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_bytes", "admm_csr_layout_bytes", "admm_csr_layout_counts",
+    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_set_lean", "admm_csr_bytes", "admm_csr_layout_bytes", "admm_csr_layout_counts",
     "admm_csr_destroy",
     "admm_predict", "admm_metrics", "admm_auc_scores", "admm_tied_ranks", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_predict", "admm_ftrl_update", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus", "admm_consensus_static",
@@ -88,6 +88,7 @@ def load():
         "admm_csr_build_transposed": [vp, u64, C.c_uint32],
         "admm_csr_relabel_by_frequency": [vp],
         "admm_csr_bytes": [vp, C.POINTER(u64), C.POINTER(u64)],
+        "admm_csr_set_lean": [vp, i32],
         "admm_csr_layout_bytes": [vp, C.POINTER(u64)],
         "admm_csr_layout_counts": [vp, C.POINTER(u64)],
         "admm_csr_destroy": [vp],
@@ -351,6 +352,11 @@ class SampleSet:
 
     def build_transposed(self, panel_rows=0, col_block=0):
         _check(self.ctx.L.admm_csr_build_transposed(self.h, int(panel_rows), int(col_block)))
+        return self
+
+    def set_lean(self, on=True):
+        """whole-set sweeps only from here on: the builders free the row-major forms once their copies exist"""
+        _check(self.ctx.L.admm_csr_set_lean(self.h, 1 if on else 0))
         return self
 
     def relabel_by_frequency(self):

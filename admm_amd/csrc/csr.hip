@@ -1144,6 +1144,52 @@ int build_dep(admm_csr *csr) {
   return ADMM_OK;
 }
 
+int require_rows(const admm_csr *csr, const char *what) {
+  if (!csr->rows_released) return ADMM_OK;
+  set_error("%s: this sample set keeps only the forms its whole-set sweeps read (admm_csr_set_lean); its rows are gone", what);
+  return ADMM_ERR_STATE;
+}
+
+// longest stored row (mask-held entries included), from the row pointers while they exist
+static int note_max_row_len(admm_csr *csr) {
+  admm_ctx *ctx = csr->ctx;
+  if (!csr->d_rowptr || csr->nrows == 0) return ADMM_OK;
+  const int g = grid_for(csr->nrows, 256, ctx->cu_count * 8);
+  hipLaunchKernelGGL(k_maxrowlen, dim3(g), dim3(256), 0, ctx->stream, csr->d_rowptr, csr->nrows, ctx->d_partials);
+  ADMM_HIP_CHECK(hipGetLastError());
+  std::vector<double> hp(g);
+  ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), ctx->d_partials, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+  ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  double m = 1;
+  for (double v : hp) m = std::max(m, v);
+  csr->max_row_len = std::max<uint64_t>(csr->max_row_len, (uint64_t)m);
+  return ADMM_OK;
+}
+
+// a lean set with row masks: the row-major CSR is not read again once the compact form exists ...
+static int release_row_major(admm_csr *csr) {
+  if (!csr->lean || !csr->hot_dense || !csr->d_rowptr) return ADMM_OK;
+  ADMM_TRY(note_max_row_len(csr));
+  ADMM_HIP_CHECK(hipStreamSynchronize(csr->ctx->stream));
+  for (void **p : {(void **)&csr->d_rowptr, (void **)&csr->d_col, (void **)&csr->d_val, (void **)&csr->d_dep, (void **)&csr->d_seqcol}) {
+    if (*p) ADMM_HIP_CHECK(hipFree(*p));
+    *p = nullptr;
+  }
+  csr->rows_released = true;
+  return ADMM_OK;
+}
+
+// ... and the compact form's entries not once the row-panel and column-block copies exist (the masks stay)
+static int release_compact(admm_csr *csr) {
+  if (!csr->lean || !csr->hot_dense || !csr->has_fp || !csr->has_t || !csr->rows_released) return ADMM_OK;
+  ADMM_HIP_CHECK(hipStreamSynchronize(csr->ctx->stream));
+  for (void **p : {(void **)&csr->d_crowptr, (void **)&csr->d_ccol, (void **)&csr->d_cval}) {
+    if (*p) ADMM_HIP_CHECK(hipFree(*p));
+    *p = nullptr;
+  }
+  return ADMM_OK;
+}
+
 int build_forward_panels(admm_csr *csr) {
   admm_ctx *ctx = csr->ctx;
   for (void **p : {(void **)&csr->d_fcol, (void **)&csr->d_frow, (void **)&csr->d_fval, (void **)&csr->d_fptr,
@@ -1165,19 +1211,10 @@ int build_forward_panels(admm_csr *csr) {
     nhot = (uint32_t)std::min<uint64_t>(nhot, std::strtoull(env, nullptr, 10));
   const bool skip_bias = csr->has_bias && !csr->hot_dense;
   // longest stored row (mask-held entries included): bounds a margin's magnitude
-  {
-    const int g = grid_for(csr->nrows, 256, ctx->cu_count * 8);
-    hipLaunchKernelGGL(k_maxrowlen, dim3(g), dim3(256), 0, ctx->stream, csr->d_rowptr, csr->nrows, ctx->d_partials);
-    ADMM_HIP_CHECK(hipGetLastError());
-    std::vector<double> hp(g);
-    ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), ctx->d_partials, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
-    ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    double m = 1;
-    for (double v : hp) m = std::max(m, v);
-    csr->max_row_len = std::max<uint64_t>(csr->max_row_len, (uint64_t)m);
-    csr->fp_lenbits = 0;
-    while (std::ldexp(1.0, csr->fp_lenbits) < m + 1.0) ++csr->fp_lenbits;
-  }
+  ADMM_TRY(note_max_row_len(csr));
+  ADMM_REQUIRE(csr->max_row_len > 0, "forward panels: the longest row is not known");
+  csr->fp_lenbits = 0;
+  while (std::ldexp(1.0, csr->fp_lenbits) < (double)csr->max_row_len + 1.0) ++csr->fp_lenbits;
   const uint64_t npanels = (csr->nrows + R - 1) / R;
   const int grid = (int)std::min<uint64_t>(npanels, (uint64_t)ctx->cu_count * 4);
   const float *src_val = csr->hot_dense ? csr->d_cval : csr->d_val;
@@ -1455,6 +1492,7 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
   // a set whose stored values are all 1 (binary features, the common case for this model) is kept
   // as a pattern matrix: no value array, the kernels read an implicit 1
   const bool keep_val = val && flags.nonunit != 0;
+  c->has_val = keep_val;
   if (!keep_val && t_val) {
     hipFree(t_val);
     t_val = nullptr;
@@ -1505,7 +1543,8 @@ extern "C" int admm_csr_shape(const admm_csr *csr, uint64_t *nrows, uint64_t *nn
 extern "C" int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t *transposed_bytes) {
   ADMM_REQUIRE(csr, "admm_csr_bytes: csr is NULL");
   if (csr_bytes)
-    *csr_bytes = 8 * (csr->nrows + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * csr->nrows;
+    *csr_bytes = csr->rows_released ? 4 * csr->nrows
+                                    : 8 * (csr->nrows + 1) + 4 * csr->nnz + (csr->has_val ? 4 * csr->nnz : 0) + 4 * csr->nrows;
   if (transposed_bytes)
     *transposed_bytes = csr->has_t ? 8 * (csr->npanels * csr->nblocks + 1) + 6 * csr->tnnz +
                                          (csr->d_tval ? 4 * csr->tnnz : 0) + (csr->d_tcv ? 6 : 2) * csr->tc_words
@@ -1516,7 +1555,9 @@ extern "C" int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t
 extern "C" int admm_csr_layout_bytes(const admm_csr *csr, uint64_t out[4]) {
   ADMM_REQUIRE(csr && out, "admm_csr_layout_bytes: NULL argument");
   const uint64_t n = csr->nrows;
-  out[0] = 8 * (n + 1) + 4 * csr->nnz + (csr->d_val ? 4 * csr->nnz : 0) + 4 * n;
+  // (the row-major forms: the CSR and, beside a row-panel copy, the compact rows of a set with row masks)
+  out[0] = (csr->rows_released ? 0 : 8 * (n + 1) + 4 * csr->nnz + (csr->has_val ? 4 * csr->nnz : 0) + 4 * n) +
+           ((csr->has_fp && csr->hot_dense && csr->d_crowptr) ? 8 * (n + 1) + 4 * csr->cnnz + (csr->d_cval ? 4 * csr->cnnz : 0) : 0);
   if (csr->has_fp)  // row-panel copy: masks + hot stream (u16 [, value]) + (column u32, row u16 [, value]) per remaining entry + labels
     out[1] = (csr->hot_dense ? 8 * n * (2 + kWarmWords) : 0) + (csr->d_hval ? 6 : 2) * csr->hp_words +
              (csr->d_fval ? 10 : 6) * csr->fp_nnz + 4 * n;
@@ -1544,6 +1585,7 @@ extern "C" int admm_csr_layout_counts(const admm_csr *csr, uint64_t out[6]) {
 extern "C" int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t *col, float *val,
                                  float *label) {
   ADMM_REQUIRE(csr, "admm_csr_download: csr is NULL");
+  ADMM_TRY(require_rows(csr, "admm_csr_download"));
   admm_ctx *ctx = csr->ctx;
   ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (rowptr) ADMM_HIP_CHECK(hipMemcpy(rowptr, csr->d_rowptr, sizeof(uint64_t) * (csr->nrows + 1), hipMemcpyDeviceToHost));
@@ -1569,6 +1611,7 @@ extern "C" int admm_csr_download(const admm_csr *csr, uint64_t *rowptr, uint32_t
 extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
   ADMM_REQUIRE(csr, "admm_csr_relabel_by_frequency: csr is NULL");
   if (csr->d_perm || csr->nnz == 0) return ADMM_OK;
+  ADMM_TRY(require_rows(csr, "admm_csr_relabel_by_frequency"));
   admm_ctx *ctx = csr->ctx;
   ADMM_HIP_CHECK(hipSetDevice(ctx->device));
   const uint64_t dim = csr->dim;
@@ -1661,6 +1704,18 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
   // a transposed copy built earlier still holds the entries the mask now covers, and a column stream
   // is in the old numbering: rebuild
   if (csr->has_t && (csr->hot_dense || csr->has_tc)) return build_transposed(csr, csr->panel_rows, csr->col_block, csr->has_tc);
+  ADMM_TRY(release_row_major(csr));
+  return ADMM_OK;
+}
+
+extern "C" int admm_csr_set_lean(admm_csr *csr, int on) {
+  ADMM_REQUIRE(csr, "admm_csr_set_lean: csr is NULL");
+  ADMM_REQUIRE(!csr->rows_released || on, "admm_csr_set_lean: the rows are gone already");
+  csr->lean = on != 0;
+  if (csr->lean && csr->hot_dense) {
+    ADMM_TRY(release_row_major(csr));
+    ADMM_TRY(release_compact(csr));
+  }
   return ADMM_OK;
 }
 
@@ -1683,6 +1738,8 @@ extern "C" int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uin
 namespace admm_impl {
 int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool stream) {
   admm_ctx *ctx = csr->ctx;
+  ADMM_REQUIRE(!(csr->rows_released && !csr->d_crowptr), "admm_csr_build_transposed: this lean sample set has been built already and "
+               "no longer holds the rows a rebuild would read");
   if (col_block == 0) col_block = 8192;
   ADMM_REQUIRE(col_block <= 16384 && col_block >= 64 && (col_block % 64) == 0,
                "admm_csr_build_transposed: col_block must be a multiple of 64 in [64, 16384]");
@@ -1721,16 +1778,17 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   ADMM_HIP_CHECK(hipMalloc(&d_cnt, sizeof(unsigned long long) * (ncells + 1)));
   ADMM_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * (ncells + 1), ctx->stream));
   TBuildArgs a{};
-  a.rowptr = csr->d_rowptr;
-  a.col = csr->d_col;
+  // (a set with row masks is read in its compact form, which leaves out what the masks hold)
+  a.rowptr = csr->hot_dense ? csr->d_crowptr : csr->d_rowptr;
+  a.col = csr->hot_dense ? csr->d_ccol : csr->d_col;
   a.perm = csr->d_perm;
-  a.val = csr->d_val;
+  a.val = csr->hot_dense ? csr->d_cval : csr->d_val;
   a.nrows = csr->nrows;
   a.panel_rows = panel_rows;
   a.col_block = col_block;
   a.nblocks = csr->nblocks;
   a.skip_bias = (csr->has_bias && !csr->hot_dense) ? 1 : 0;
-  a.hot_dense = csr->hot_dense ? 1 : 0;
+  a.hot_dense = 0;
   a.stream_cols = csr->tc_cols;
   a.cell_count = d_cnt;
   const uint64_t chunks = csr->npanels * ((panel_rows + kChunkRows - 1) / kChunkRows);
@@ -1761,7 +1819,7 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   ADMM_HIP_CHECK(hipMalloc(&csr->d_tptr, sizeof(uint64_t) * (ncells + 1)));
   ADMM_HIP_CHECK(hipMalloc(&csr->d_trow, sizeof(uint32_t) * (run + 8)));
   ADMM_HIP_CHECK(hipMalloc(&csr->d_tcol, sizeof(uint16_t) * (run + 8)));
-  if (csr->d_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_tval, sizeof(float) * (run + 8)));
+  if (csr->has_val) ADMM_HIP_CHECK(hipMalloc(&csr->d_tval, sizeof(float) * (run + 8)));
   ADMM_HIP_CHECK(hipMemcpyAsync(csr->d_tptr, csr->h_tptr.data(), sizeof(uint64_t) * (ncells + 1), hipMemcpyHostToDevice, ctx->stream));
   // cursors start at the cell bases
   ADMM_HIP_CHECK(hipMemcpyAsync(d_cnt, csr->h_tptr.data(), sizeof(uint64_t) * (ncells + 1), hipMemcpyHostToDevice, ctx->stream));
@@ -1779,9 +1837,12 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   // fixed-point scale of the accumulators: |r * val| <= vmax for |r| <= 1, at most panel_rows
   // addends per column and cell, everything below 2^61
   csr->vmax = 1.0f;
-  if (csr->d_val && csr->nnz) {
-    const int g = grid_for(csr->nnz, 256, ctx->cu_count * 8);
-    hipLaunchKernelGGL(k_absmax, dim3(g), dim3(256), 0, ctx->stream, csr->d_val, csr->nnz, ctx->d_partials);
+  if (csr->has_val && csr->nnz) {
+    // (what the row masks hold has value 1, and the maximum is at least 1 anyway)
+    const float *vsrc = csr->hot_dense ? csr->d_cval : csr->d_val;
+    const uint64_t vn = csr->hot_dense ? csr->cnnz : csr->nnz;
+    const int g = grid_for(std::max<uint64_t>(vn, 1), 256, ctx->cu_count * 8);
+    hipLaunchKernelGGL(k_absmax, dim3(g), dim3(256), 0, ctx->stream, vsrc, vn, ctx->d_partials);
     std::vector<double> hp(g);
     ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), ctx->d_partials, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
     ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1800,6 +1861,8 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   csr->has_t = true;
   ADMM_TRY(ensure_taccum(csr));
   ADMM_TRY(build_forward_panels(csr));
+  ADMM_TRY(release_row_major(csr));  // (a lean set whose copy was asked for after its relabelling got here with them gone already)
+  ADMM_TRY(release_compact(csr));
   return ADMM_OK;
 }
 }  // namespace admm_impl
@@ -1861,6 +1924,7 @@ extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_c
   if ((e = hipMalloc(&c->d_col, sizeof(uint32_t) * (total + 8))) != hipSuccess) return fail("col", e);
   // the generated values are all 1: stored only on request
   if (spec->explicit_values && (e = hipMalloc(&c->d_val, sizeof(float) * (total + 8))) != hipSuccess) return fail("val", e);
+  c->has_val = spec->explicit_values != 0;
   a.rowptr = c->d_rowptr;
   a.col = c->d_col;
   a.val = c->d_val;

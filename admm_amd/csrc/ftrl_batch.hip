@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(256) k_ps_init_max(float *pmax, const float *f
 bool ftrl_persistent_eligible(const admm_csr *csr, uint64_t batch) {
   const char *env = getenv("ADMM_FTRL_PERSISTENT");
   if (!env || env[0] != '1') return false;
-  return csr->has_t && !csr->has_tc && csr->hot_dense && csr->has_fp && csr->d_val == nullptr && csr->d_perm && csr->d_inv &&
+  return csr->has_t && !csr->has_tc && csr->hot_dense && csr->has_fp && !csr->has_val && csr->d_perm && csr->d_inv &&
          csr->fp_rows <= (uint32_t)kPsThreads && csr->fp_rows % 64 == 0 && csr->panel_rows == batch &&
          batch % csr->fp_rows == 0 && csr->col_block <= 8192 && csr->dim >= kMaskCols && csr->npanels > 0 &&
          csr->npanels < (1ull << 22) && csr->nrows < (1ull << 30);

@@ -108,6 +108,11 @@ struct admm_ctx {
 struct admm_csr {
   admm_ctx *ctx = nullptr;
   uint64_t nrows = 0, nnz = 0, dim = 0;
+  bool has_val = false;       // the set stores values (else every value is 1: a pattern matrix)
+  // lean: the caller uses the set for whole-set sweeps only, so the builders free every row-major form as soon as
+  // the copies that replace it exist; rows_released: that has happened (d_rowptr, d_col, d_val, d_crowptr, d_ccol,
+  // d_cval are gone), and whatever reads rows fails with ADMM_ERR_STATE
+  bool lean = false, rows_released = false;
   bool has_bias = false;      // column 0 is the all-ones bias column (present in every row)
   bool has_dup_cols = false;  // some row stores a column twice
   uint64_t *d_rowptr = nullptr;
@@ -234,6 +239,8 @@ int build_forward_panels(admm_csr *csr);  // csr.hip
 int build_dep(admm_csr *csr);             // csr.hip: previous-occurrence table of the sequential FTRL pass
 int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool column_stream);  // csr.hip
 int ensure_taccum(admm_csr *csr);
+// fails (ADMM_ERR_STATE) when the set no longer holds its rows (admm_csr_set_lean); `what` names the caller
+int require_rows(const admm_csr *csr, const char *what);
 // mini-batch FTRL pass in one launch (ftrl_batch.hip)
 bool ftrl_persistent_eligible(const admm_csr *csr, uint64_t batch);
 int ftrl_pass_persistent(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,

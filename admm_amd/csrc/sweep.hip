@@ -1221,6 +1221,7 @@ int launch_forward(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const 
   if (csr->has_fp && nw == 0 && mode == FWD_FTRL && r0 < r1 && r0 % csr->fp_rows == 0 &&
       (r1 % csr->fp_rows == 0 || r1 == csr->nrows))
     return launch_forward_panels(csr, mode, r0, r1, w, nw, out_rows, nblocks_out, margins_out);
+  ADMM_TRY(require_rows(csr, "forward sweep over row ranges"));
   if (nw > 0) {  // nw == 0: the caller has filled csr->d_wsum itself
     KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_wsum, dim3(grid_for(csr->dim, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, w[0],
@@ -2695,6 +2696,7 @@ extern "C" int admm_ftrl_pass_multi(admm_csr *const *sets, float *const *w, floa
   for (int k = 0; k < count; ++k) {
     ADMM_REQUIRE(sets[k] && w[k] && z[k] && n[k] && offset[k] && reg_offset[k],
                  "admm_ftrl_pass_multi: NULL argument for pass %d", k);
+    ADMM_TRY(require_rows(sets[k], "admm_ftrl_pass_multi"));
     for (int j = 0; j < k; ++j)
       ADMM_REQUIRE(w[j] != w[k] && z[j] != z[k] && n[j] != n[k],
                    "admm_ftrl_pass_multi: passes %d and %d share a state vector", j, k);
@@ -2707,6 +2709,7 @@ extern "C" int admm_ftrl_pass(admm_csr *csr, float *w, float *z, float *n, const
                               uint64_t batch) {
   ADMM_REQUIRE(csr && w && z && n && offset && reg_offset, "admm_ftrl_pass: NULL argument");
   ADMM_REQUIRE(alpha > 0, "admm_ftrl_pass: alpha must be > 0");
+  ADMM_TRY(require_rows(csr, "admm_ftrl_pass"));
   if (batch <= 1) return ftrl_pass_sequential(csr, w, z, n, offset, reg_offset, alpha, beta, l1, l2);
   return ftrl_pass_batched(csr, w, z, n, offset, reg_offset, alpha, beta, l1, l2, batch);
 }

@@ -168,7 +168,7 @@ class SampleSet {
   int Size();
   // device side
   admm_csr *device() const { return csr_; }
-  void PrepareTransposed(uint64_t panel_rows = 0, uint32_t col_block = 0, bool relabel = true);
+  void PrepareTransposed(uint64_t panel_rows = 0, uint32_t col_block = 0, bool relabel = true, bool lean = false);
   uint64_t nnz_with_bias() const { return nnz_ + rows_; }
 
  protected:

@@ -323,8 +323,11 @@ void SampleSet::EnsureHost() {
   rowptr_[nr] = rp[nr] - nr;
 }
 
-void SampleSet::PrepareTransposed(uint64_t panel_rows, uint32_t col_block, bool relabel) {
+void SampleSet::PrepareTransposed(uint64_t panel_rows, uint32_t col_block, bool relabel, bool lean) {
   ADMM_CHECK(csr_ != nullptr);
+  // lean: the set will only be swept as a whole from here on (the L-BFGS local solver); the library then frees
+  // each row-major form once the copy that replaces it exists, and the row cursor has nothing left to read
+  if (lean) ADMM_CALL(admm_csr_set_lean(csr_, 1));
   // relabelling first: the copies are then built once, in the final numbering
   if (relabel) ADMM_CALL(admm_csr_relabel_by_frequency(csr_));
   ADMM_CALL(admm_csr_build_transposed(csr_, panel_rows, col_block));

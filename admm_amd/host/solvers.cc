@@ -1,6 +1,8 @@
 // FtrlSolver, Worker, Master and Metrics on top of the C ABI.
 #include <cmath>
 
+#include <cstdlib>
+
 #include "admm_host.h"
 
 using admm::DeviceVector;
@@ -89,8 +91,11 @@ void Worker::LoadParts(const AdmmConfig &admm_params) {
     for (int part = 0; part < nparts; ++part) {
       parts_.emplace_back(new SampleSet);
       ADMM_CHECK(parts_.back()->Initialize(train_name, part, nparts, admm_params.dim));
-      if (admm_params.local_solver == "lbfgs")
-        parts_.back()->PrepareTransposed(0, 16384, true);
+      if (admm_params.local_solver == "lbfgs") {
+        // ADMM_LEAN_SETS=1: keep only the forms the solver's sweeps read (about 1.4 instead of 3 times the CSR in HBM)
+        const char *lean = std::getenv("ADMM_LEAN_SETS");
+        parts_.back()->PrepareTransposed(0, 16384, true, lean && lean[0] == '1');
+      }
       else if (admm_params.ftrl_batch > 1)
         parts_.back()->PrepareTransposed(admm_params.ftrl_batch, 0, true);
     }

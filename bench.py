@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-linesearch", action="store_true",
                     help="skip the two extra iterations that time the other line search mode")
+    ap.add_argument("--keep-rows", action="store_true",
+                    help="keep the training set's row-major forms in HBM beside its copies (admm_csr_set_lean off)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="c3 on one GPU also runs the ftrl configuration and a c5 shard at full size after its "
                          "timed region and attaches them as config.other_configs; this switch skips that")
@@ -415,6 +417,8 @@ def run_admm(args, job, side=False):
         scaling = "strong"
     t_gen = time.perf_counter()
     train = ctx.csr_synth(r1 - r0, args.dim, args.mean_nnz, seed=args.seed, row_offset=r0, **synth_kw(args))
+    if not args.keep_rows:
+        train.set_lean()                  # whole-set sweeps only: each row-major form is freed once its copies exist
     train.relabel_by_frequency()          # first: the copies are then built once, in the final numbering
     train.build_transposed(panel_rows=args.panel_rows, col_block=args.col_block)
     n_test = max(1, int((r1 - r0) * args.test_frac))

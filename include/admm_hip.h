@@ -119,9 +119,20 @@ int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_b
  * caller's numbering and admm_csr_download returns the original ids.  No counterpart in the
  * reference. */
 int admm_csr_relabel_by_frequency(admm_csr *csr);
+/* Declares that this sample set serves whole-set sweeps only (admm_logistic_fg, admm_lbfgs_solve, admm_predict,
+ * admm_metrics): the builders then free every row-major form as soon as the copies that replace it exist -- the CSR
+ * once admm_csr_relabel_by_frequency has made the row masks and the compact rows, those rows once
+ * admm_csr_build_transposed has made the row-panel and column-block copies -- which leaves about 1.4 times the
+ * CSR's bytes in HBM instead of 3 times, and lets a set be built whose forms would not fit side by side.
+ * Afterwards whatever reads rows (admm_csr_download, admm_ftrl_pass, a rebuild of the copies) returns
+ * ADMM_ERR_STATE.  A set that cannot have row masks (fewer than 256 columns, or a row that stores a column twice)
+ * keeps all its forms.  No counterpart in the reference, whose SampleSet re-reads its file for every pass
+ * (src/workers.cc:73-77). */
+int admm_csr_set_lean(admm_csr *csr, int on);
 /* Bytes of HBM held by this sample set. */
 int admm_csr_bytes(const admm_csr *csr, uint64_t *csr_bytes, uint64_t *transposed_bytes);
-/* The same, by layout: out[0] the row-major CSR, out[1] the form the forward sweep streams (for a
+/* The same, by layout: out[0] the row-major forms still held (the CSR; beside a row-panel copy also the compact
+ * rows of a relabelled set), out[1] the form the forward sweep streams (for a
  * relabelled set the compact form: row masks of the most frequent columns + the remaining entries
  * as CSR + labels; else the CSR itself), out[2] the column-block copy the transposed sweep streams,
  * out[3] the per-row work vectors allocated so far. */
