@@ -108,7 +108,9 @@ int auc_scores(admm_ctx *ctx, const float *labels, const float *scores, uint64_t
 }
 
 // rank[orig[i]] = (s + e + 1) / 2 in float arithmetic as the reference has it (src/metrics.cc:32-44), for
-// sorted position i in the tie group [s, e)
+// sorted position i in the tie group [s, e): the integer s + e is rounded to float, then 1.0f is added; the
+// last group is written as (s + (n - 1)) rounded to float plus 2.0f there (src/metrics.cc:37-40), which differs
+// from the former once s + n passes 2^24
 __global__ void __launch_bounds__(256) k_rank_write(const uint32_t *__restrict__ start, const uint32_t *__restrict__ orig,
                                                     uint64_t n, float *__restrict__ ranks) {
   const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256) k_rank_write(const uint32_t *__restrict__
       if (start[mid] > s) hi = mid;
       else lo = mid + 1;
     }
-    ranks[orig[i]] = ((float)(int)(s + (uint32_t)lo) + 1.0f) / 2;
+    ranks[orig[i]] = lo == n ? ((float)(int)(s + (uint32_t)n - 1u) + 2.0f) / 2 : ((float)(int)(s + (uint32_t)lo) + 1.0f) / 2;
   }
 }
 

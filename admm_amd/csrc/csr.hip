@@ -1377,7 +1377,13 @@ namespace admm_impl {
 struct UploadFlags {
   unsigned long long bad_row;  // smallest offending row, ~0 if none
   unsigned int dup, nonunit;
+  unsigned int long_unsorted, pad;  // some row longer than kPairwiseCap is not in increasing order: the host looks at those
 };
+
+// rows up to this length are searched for a repeated column pair by pair on the device (16 lanes per row); a
+// longer row out of order -- a million entries would keep its 16 lanes comparing for minutes -- is left to the
+// host, which sorts a copy of it
+constexpr uint64_t kPairwiseCap = 2048;
 
 __global__ void __launch_bounds__(256) k_validate(const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                                                   const float *__restrict__ val, uint64_t nrows, uint64_t nnz,
@@ -1399,7 +1405,9 @@ __global__ void __launch_bounds__(256) k_validate(const uint64_t *__restrict__ r
       if (k > b && col[k - 1] >= c) unsorted = 1;
     }
     for (int off = 8; off > 0; off >>= 1) unsorted |= __shfl_xor(unsorted, off, 16);
-    if (unsorted) {
+    if (unsorted && e - b > kPairwiseCap) {
+      f->long_unsorted = 1u;
+    } else if (unsorted) {
       for (uint64_t k = b + sub; k < e; k += 16) {
         const uint32_t c = col[k];
         for (uint64_t q = b; q < k; ++q)
@@ -1460,7 +1468,7 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
   if (val) UP_CHECK(hipMalloc(&t_val, sizeof(float) * (nnz + 8)));
   UP_CHECK(hipMalloc(&d_flags, sizeof(UploadFlags)));
   UP_CHECK(hipMalloc(&c->d_label, sizeof(float) * std::max<uint64_t>(nrows, 1)));
-  UploadFlags flags = {~0ull, 0u, 0u};
+  UploadFlags flags = {~0ull, 0u, 0u, 0u, 0u};
   UP_CHECK(hipMemcpyAsync(d_flags, &flags, sizeof(flags), hipMemcpyHostToDevice, ctx->stream));
   if (nrows) UP_CHECK(hipMemcpyAsync(c->d_label, label, sizeof(float) * nrows, hipMemcpyHostToDevice, ctx->stream));
   UP_CHECK(hipMemcpyAsync(t_rowptr, rowptr, sizeof(uint64_t) * (nrows + 1), hipMemcpyHostToDevice, ctx->stream));
@@ -1487,6 +1495,20 @@ extern "C" int admm_csr_upload(admm_ctx *ctx, const uint64_t *rowptr, const uint
         }
     }
     return fail(ADMM_ERR_INVALID);
+  }
+  if (flags.long_unsorted && !flags.dup) {
+    // the few long rows out of order, on the host: sort a copy, look at neighbours
+    std::vector<uint32_t> tmp_ids;
+    for (uint64_t r = 0; r < nrows && !flags.dup; ++r) {
+      const uint64_t b = rowptr[r], e = rowptr[r + 1];
+      if (e - b <= kPairwiseCap) continue;
+      bool increasing = true;
+      for (uint64_t k = b + 1; k < e && increasing; ++k) increasing = col[k - 1] < col[k];
+      if (increasing) continue;
+      tmp_ids.assign(col + b, col + e);
+      std::sort(tmp_ids.begin(), tmp_ids.end());
+      if (std::adjacent_find(tmp_ids.begin(), tmp_ids.end()) != tmp_ids.end()) flags.dup = 1u;
+    }
   }
   c->has_dup_cols = flags.dup != 0;
   // a set whose stored values are all 1 (binary features, the common case for this model) is kept

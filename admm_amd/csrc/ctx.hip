@@ -281,13 +281,18 @@ __global__ void __launch_bounds__(256) k_finish_static(const double *__restrict_
 
 // Device address of `scratch` on `device`, resolved once per device with that device current.
 constexpr int kMaxDevices = 64;
-static double *g_scratch_ptr[kMaxDevices] = {};
+static std::atomic<double *> g_scratch_ptr[kMaxDevices] = {};
 static std::mutex g_scratch_mutex;
 
 static int static_scratch(int device, double **out) {
   ADMM_REQUIRE(device >= 0 && device < kMaxDevices, "device %d: at most %d devices per process", device, kMaxDevices);
+  // once resolved, a call reads the pointer and nothing else: no lock, no runtime query
+  if (double *known = g_scratch_ptr[device].load(std::memory_order_acquire)) {
+    *out = known;
+    return ADMM_OK;
+  }
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
-  if (!g_scratch_ptr[device]) {
+  if (!g_scratch_ptr[device].load(std::memory_order_relaxed)) {
     int cur = -1;
     ADMM_HIP_CHECK(hipGetDevice(&cur));
     if (cur != device) ADMM_HIP_CHECK(hipSetDevice(device));
@@ -298,9 +303,9 @@ static int static_scratch(int device, double **out) {
       set_error("hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
       return ADMM_ERR_HIP;
     }
-    g_scratch_ptr[device] = ptr;
+    g_scratch_ptr[device].store(ptr, std::memory_order_release);
   }
-  *out = g_scratch_ptr[device];
+  *out = g_scratch_ptr[device].load(std::memory_order_relaxed);
   return ADMM_OK;
 }
 

@@ -162,9 +162,11 @@ void Worker::GetWeights(AdmmConfig &admm_params, DeviceVector &out) const {
 }
 
 bool Master::GlobalUpdate(const DeviceVector &workers, AdmmConfig &admm_params, int num_worker) {
+  // (the main loop's buffer carries a few floats of its own behind the payload: the update covers the weights only)
+  ADMM_CHECK(workers.size() >= admm_params.global_weights.size());
   return admm_global_update(Runtime::Get().ctx(), workers.data(), num_worker, admm_params.step_size,
                             admm_params.global_var, admm_params.global_l1, admm_params.global_weights.data(),
-                            workers.size()) == ADMM_OK;
+                            admm_params.global_weights.size()) == ADMM_OK;
 }
 
 bool Master::Consensus(const DeviceVector &workers, AdmmConfig &admm_params, int num_worker, Worker &worker, double *r2,

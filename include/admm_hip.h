@@ -271,7 +271,11 @@ int admm_consensus(admm_ctx *ctx, const float *sum, int num_worker, float rho, f
  *     which limits dim to ADMM_CONSENSUS_STATIC_MAX_DIM; a larger dim is rejected with
  *     ADMM_ERR_INVALID and nothing is launched.
  * The call makes no hipMalloc / hipFree and calls no allocating routine.  All calls on one GPU
- * share that GPU's array: two calls that overlap on one GPU (different streams) race on it. */
+ * share that GPU's array: two calls that overlap on one GPU (different streams) race on it.
+ * Precondition for callers under stream capture: the FIRST call on a device resolves that device's copy of the
+ * array (one hipGetSymbolAddress, which may load the code object and is not legal while capturing); so make one
+ * admm_ctx_create on the device, or one call of this function outside the capture, beforehand.  Every later call
+ * reads the resolved address without a lock or a runtime query. */
 #define ADMM_CONSENSUS_STATIC_MAX_DIM (1ull << 28)
 int admm_consensus_static(void *stream, const float *sum, int num_worker, float rho,
                           float global_var, float l1, const float *x, float *ydual, float *z,

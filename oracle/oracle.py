@@ -436,10 +436,14 @@ def admm_run(train_parts, tests, conf, workers=None, zg=None):
             payloads.append(payload(workers[r].x, workers[r].y, conf.step_size))
         for r in range(nrank):                       # rabit::Allreduce<Sum>, :69
             total = (total + payloads[r]).astype(np.float32)
-        lines = []
+        lines, lines64 = [], []
         for r in range(nrank):                       # :71-81
             groups = [workers[r].x, workers[r].bias]
             lines.append((logloss(tests[r], groups), auc(tests[r], groups), tests[r].nrows))
+            # the same two numbers with the sums kept in double (the reference keeps them in float, which loses
+            # digits beyond some 10^4 rows: src/metrics.cc:68-74,92,105)
+            s64, p = logloss_sum_f64(tests[r], groups, want_p=True)
+            lines64.append((s64 / max(tests[r].nrows, 1), auc_from_scores(p, tests[r].label, f64=True), tests[r].nrows))
         z_prev = zg
         zg = global_update(total, nrank, conf.step_size, conf.global_var, conf.global_l1)  # :84
         res = []
@@ -448,5 +452,5 @@ def admm_run(train_parts, tests, conf, workers=None, zg=None):
             res.append(residuals(workers[r].x, zg, z_prev, conf.step_size))
         records.append(dict(total=total.copy(), z=zg.copy(),
                             x=[w.x.copy() for w in workers], y=[w.y.copy() for w in workers],
-                            lines=lines, residuals=res, stats=stats))
+                            lines=lines, lines64=lines64, residuals=res, stats=stats))
     return workers, zg, records

@@ -76,19 +76,28 @@ def _run_gpu(ctx, raws_train, raws_test, conf, dim, multi=False):
     return records, final
 
 
-def _compare(rec_gpu, rec_ref, rtol, atol, line_rel=2e-5, auc_rel=5e-5, res_rel=1e-4):
+def _compare(rec_gpu, rec_ref, rtol, atol, line_rel=1e-5, auc_rel=1e-5, res_rel=1e-5, stats=False):
+    """the tolerances are the path's stated one, 1e-5 relative: logloss and AUC against the restatement's sums in
+    double (the device accumulates in double; the reference's float sums are looser than that by themselves),
+    the residual norms against the restatement's, which come from vectors that agree to rtol themselves"""
     assert len(rec_gpu) == len(rec_ref)
     for a, b in zip(rec_gpu, rec_ref):
+        if stats:   # the local solves took the same path: as many objective evaluations and iterations
+            for sa, sb in zip(a["stats"], b["stats"]):
+                assert (sa["evals"], sa["iters"]) == (sb["evals"], sb["iters"]), (sa, sb)
+                assert sa["f"] == pytest.approx(sb["f"], rel=1e-5)
         np.testing.assert_allclose(a["total"], b["total"], rtol=rtol, atol=atol)
         np.testing.assert_allclose(a["z"], b["z"], rtol=rtol, atol=atol)
         for xa, xb in zip(a["x"], b["x"]):
             np.testing.assert_allclose(xa, xb, rtol=rtol, atol=atol)
         for ya, yb in zip(a["y"], b["y"]):
             np.testing.assert_allclose(ya, yb, rtol=rtol, atol=atol)
-        for (la, aa, na), (lb, ab, nb) in zip(a["lines"], b["lines"]):
+        for (la, aa, na), (lb, ab, nb), (lf, af, _) in zip(a["lines"], b["lines64"], b["lines"]):
             assert na == nb
             assert la == pytest.approx(lb, rel=line_rel)
             assert aa == pytest.approx(ab, rel=auc_rel)
+            # and the reference's own float sums are where float sums of this length can be
+            assert la == pytest.approx(lf, rel=2e-5) and aa == pytest.approx(af, rel=5e-5)
         for (r2a, s2a), (r2b, s2b) in zip(a["residuals"], b["residuals"]):
             assert r2a == pytest.approx(r2b, rel=res_rel, abs=1e-12)
             assert s2a == pytest.approx(s2b, rel=res_rel, abs=1e-14)
@@ -116,13 +125,15 @@ def test_admm_lbfgs_mode(ctx, oracle):
     dim, nrank = 129, 2
     raws_train = [make_synth_csr(900, dim, 10, seed=70 + r) for r in range(nrank)]
     raws_test = [make_synth_csr(250, dim, 10, seed=80 + r) for r in range(nrank)]
+    # a few L-BFGS iterations per ADMM iteration, as the benchmark runs them: the two solvers must take the same
+    # trajectory (equal numbers of evaluations and iterations, objective to 1e-5, iterates to 1e-4), not merely
+    # end near the same minimum
     conf = oracle.AdmmConf(step_size=5.0, global_var=1.0, ftrl_alpha=0.1, passes=3, dim=dim, global_l1=0.05,
-                           local_solver="lbfgs", lbfgs=dict(max_iter=100, epsilon=1e-6))
+                           local_solver="lbfgs", lbfgs=dict(max_iter=4, epsilon=1e-7))
     _, _, rec_ref = oracle.admm_run([[oracle.translate(t)] for t in raws_train],
                                     [oracle.translate(t) for t in raws_test], conf)
     rec_gpu, _ = _run_gpu(ctx, raws_train, raws_test, conf, dim)
-    # both local solves run to convergence; iterates agree to the solver tolerance
-    _compare(rec_gpu, rec_ref, rtol=5e-3, atol=2e-3, line_rel=1e-3, auc_rel=1e-3, res_rel=5e-2)
+    _compare(rec_gpu, rec_ref, rtol=1e-4, atol=1e-6, res_rel=2e-4, stats=True)
 
 
 def test_rccl_binding_selftest_and_loop_with_residual_tail(ctx, oracle):
@@ -147,13 +158,14 @@ def test_rccl_binding_selftest_and_loop_with_residual_tail(ctx, oracle):
     for it in range(3):
         out = loop.iteration(last=it == 2)
         np.testing.assert_allclose(zg.download(), rec[it]["z"], rtol=1e-5, atol=1e-9)
-        assert out["line"][0] == pytest.approx(rec[it]["lines"][0][0], rel=2e-5)
-        assert out["r2"] == pytest.approx(rec[it]["residuals"][0][0], rel=1e-4, abs=1e-12)
+        assert out["line"][0] == pytest.approx(rec[it]["lines64"][0][0], rel=1e-5)
+        assert out["line"][1] == pytest.approx(rec[it]["lines64"][0][1], rel=1e-5)
+        assert out["r2"] == pytest.approx(rec[it]["residuals"][0][0], rel=1e-5, abs=1e-12)
     last = loop.flush_residuals()
     assert last["iterations_recorded"] == 3
     for (r2, s2), r in zip(loop.global_residuals, rec):     # one rank: the sums over ranks are the rank's own
-        assert r2 == pytest.approx(r["residuals"][0][0], rel=1e-4, abs=1e-12)
-        assert s2 == pytest.approx(r["residuals"][0][1], rel=1e-4, abs=1e-14)
+        assert r2 == pytest.approx(r["residuals"][0][0], rel=1e-5, abs=1e-12)
+        assert s2 == pytest.approx(r["residuals"][0][1], rel=1e-5, abs=1e-14)
     train.destroy()
     test.destroy()
 

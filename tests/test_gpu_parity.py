@@ -793,6 +793,42 @@ def test_tied_ranks_are_the_reference_sort(ctx, oracle):
     np.testing.assert_array_equal(oracle.tied_rank(np.array([3, 1, 3, 2], np.float32)), [3.5, 1.0, 3.5, 2.0])
 
 
+def test_tied_ranks_beyond_two_to_the_24(ctx, oracle):
+    """more scores than a float counts exactly: the reference rounds the integer (first + last position) of a tie
+    group to float before it adds 1 (or, for the last group, 2 to the sum with the last INDEX: src/metrics.cc:33,39),
+    and those two roundings differ up there -- a big tied group at the end shows it"""
+    n = (1 << 24) + 70_003
+    rng = np.random.default_rng(12)
+    x = np.round(rng.normal(0, 1, n), 2).astype(np.float32)
+    x[rng.choice(n, 40_001, replace=False)] = 9.0            # the last tie group, an odd number of members
+    ranks = ctx.vec(n)
+    ctx.tied_ranks(ctx.vec(n, x), ranks)
+    np.testing.assert_array_equal(ranks.download(), oracle.tied_rank(x))
+
+
+def test_upload_checks_a_long_unsorted_row_quickly(ctx):
+    """a row of several hundred thousand entries out of order: the device leaves its search for a repeated column
+    to the host (a sort) instead of comparing pair by pair; both answers come back in moments"""
+    import time
+    dim, n = 1 << 20, 400_000
+    rng = np.random.default_rng(4)
+    ids = rng.choice(dim - 1, n, replace=False).astype(np.uint32)          # unsorted, no repeats
+    short = np.arange(40, dtype=np.uint32)
+    for repeat in (False, True):
+        row = ids.copy()
+        if repeat:
+            row[-1] = row[1234]
+        col = np.concatenate([short, row, short])
+        rowptr = np.array([0, 40, 40 + n, 80 + n], np.uint64)
+        t0 = time.perf_counter()
+        dev = ctx.csr_upload(rowptr, col, None, np.array([1, 0, 1], np.float32), dim, add_bias=True)
+        dev.relabel_by_frequency()
+        assert time.perf_counter() - t0 < 20.0
+        # a set whose rows repeat a column gets no row masks
+        assert (dev.layout_counts()["mask_entries"] == 0) == repeat
+        dev.destroy()
+
+
 def test_upload_checks_on_the_device(ctx, oracle):
     """what admm_csr_upload validates: a row pointer that decreases, an index beyond dim, and (accepted, but
     noted: such sets run the element-by-element FTRL kernel) a row that stores a column twice -- the
