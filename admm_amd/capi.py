@@ -19,7 +19,7 @@ SYMBOLS = [
     "admm_vec_alloc", "admm_vec_free", "admm_vec_zero", "admm_vec_copy", "admm_vec_upload",
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
-    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_set_lean", "admm_csr_bytes", "admm_csr_layout_bytes", "admm_csr_layout_counts",
+    "admm_csr_build_transposed", "admm_csr_relabel_by_frequency", "admm_csr_set_lean", "admm_synth_row_draws", "admm_csr_bytes", "admm_csr_layout_bytes", "admm_csr_layout_counts",
     "admm_csr_destroy",
     "admm_predict", "admm_metrics", "admm_auc_scores", "admm_tied_ranks", "admm_csr_copy_labels", "admm_ftrl_pass", "admm_ftrl_predict", "admm_ftrl_update", "admm_ftrl_pass_multi", "admm_logistic_fg", "admm_lbfgs_solve",
     "admm_payload", "admm_global_update", "admm_dual_update", "admm_consensus", "admm_consensus_static",
@@ -89,6 +89,7 @@ def load():
         "admm_csr_relabel_by_frequency": [vp],
         "admm_csr_bytes": [vp, C.POINTER(u64), C.POINTER(u64)],
         "admm_csr_set_lean": [vp, i32],
+        "admm_synth_row_draws": [vp, vp, u64, C.POINTER(u64)],
         "admm_csr_layout_bytes": [vp, C.POINTER(u64)],
         "admm_csr_layout_counts": [vp, C.POINTER(u64)],
         "admm_csr_destroy": [vp],
@@ -238,6 +239,18 @@ class Context:
         h = C.c_void_p()
         _check(self.L.admm_csr_synth(self.h, C.byref(spec), C.byref(h)))
         return SampleSet(self, h)
+
+    def synth_row_draws(self, nrows, dim, mean_nnz, block_rows, seed=20251111, row_offset=0, zipf_s=1.1, len_dist=0,
+                        tail_sigma=1.0, max_len=None, model_seed=7, explicit_values=False):
+        """entries the generator draws per block of block_rows rows (bias entry included), as a numpy array"""
+        if max_len is None:
+            max_len = int(min(1024, max(8, 4 * mean_nnz)))
+        spec = SynthSpec(int(nrows), int(dim), int(seed), int(model_seed), int(row_offset), float(mean_nnz),
+                         float(zipf_s), int(len_dist), float(tail_sigma), int(max_len), 1 if explicit_values else 0)
+        nblocks = (int(nrows) + int(block_rows) - 1) // int(block_rows)
+        out = np.zeros(max(nblocks, 1), np.uint64)
+        _check(self.L.admm_synth_row_draws(self.h, C.byref(spec), int(block_rows), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out[:nblocks]
 
     def ftrl_pass_multi(self, sets, w, z, n, offset, reg_offset, alpha, beta, l_1, l_2):
         """admm_ftrl_pass_multi: pass k runs sets[k] with state w[k], z[k], n[k]"""

@@ -282,6 +282,32 @@ __global__ void __launch_bounds__(64) k_synth(SynthArgs a) {
   }
 }
 
+// Feature draws per row (before de-duplication) plus the bias entry, summed over blocks of `block_rows` rows: what
+// a job needs to cut a generated set into shards of equal entry counts without generating it (the draws are a
+// pure function of seed and global row number; the stored entries are the draws minus a row's repeats).
+__global__ void __launch_bounds__(256) k_synth_draws(SynthArgs a, uint64_t block_rows, uint64_t nblocks,
+                                                     unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long sh[4];
+  for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const uint64_t r0 = blk * block_rows, r1 = r0 + block_rows < a.s.nrows ? r0 + block_rows : a.s.nrows;
+    unsigned long long acc = 0;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+      const uint64_t hrow = mix64(a.s.seed * 0x100000001B3ull + (a.s.row_offset + r));
+      float lf;
+      if (a.s.len_dist == 1) lf = expf(a.ln_mu + a.s.tail_sigma * normal01(hrow));
+      else lf = a.s.mean_nnz + sqrtf(a.s.mean_nnz) * normal01(hrow);
+      int len = (int)floorf(lf + 0.5f);
+      len = len < 0 ? 0 : (len > (int)a.s.max_len ? (int)a.s.max_len : len);
+      acc += (unsigned long long)len + 1ull;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blk] = sh[0] + sh[1] + sh[2] + sh[3];
+  }
+}
+
 // ---- relabelling columns by frequency ------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) k_colcount(const uint64_t *__restrict__ rowptr,
@@ -1888,6 +1914,27 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
   return ADMM_OK;
 }
 }  // namespace admm_impl
+
+extern "C" int admm_synth_row_draws(admm_ctx *ctx, const admm_synth_spec *spec, uint64_t block_rows, uint64_t *sums_host) {
+  ADMM_REQUIRE(ctx && spec && sums_host && block_rows > 0, "admm_synth_row_draws: bad arguments");
+  ADMM_REQUIRE(spec->max_len >= 1 && spec->max_len <= 1024, "admm_synth_row_draws: max_len must be in [1, 1024]");
+  const uint64_t nblocks = (spec->nrows + block_rows - 1) / block_rows;
+  if (nblocks == 0) return ADMM_OK;
+  ADMM_HIP_CHECK(hipSetDevice(ctx->device));
+  SynthArgs a{};
+  a.s = *spec;
+  a.ln_mu = logf(spec->mean_nnz) - 0.5f * spec->tail_sigma * spec->tail_sigma;
+  unsigned long long *d = nullptr;
+  ADMM_HIP_CHECK(hipMalloc(&d, sizeof(unsigned long long) * nblocks));
+  hipLaunchKernelGGL(k_synth_draws, dim3((unsigned)std::min<uint64_t>(nblocks, (uint64_t)ctx->cu_count * 8)), dim3(256), 0, ctx->stream,
+                     a, block_rows, nblocks, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(sums_host, d, sizeof(unsigned long long) * nblocks, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  ADMM_HIP_CHECK(e);
+  return ADMM_OK;
+}
 
 extern "C" int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_csr **out) {
   ADMM_REQUIRE(ctx && spec && out, "admm_csr_synth: NULL argument");

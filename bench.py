@@ -407,10 +407,26 @@ def run_admm(args, job, side=False):
     from admm_amd import driver
     from admm_amd import dist as adist
 
+    sharding = "contiguous row ranges of equal size; synthetic rows are identically distributed, so the shards' entry " \
+               "counts differ by the factor below"
     if args.per_rank:
         rows_total = args.rows * world
-        r0, r1 = args.rows * rank, args.rows * (rank + 1)
         scaling = "weak"
+        if world > 1 and args.heavy:
+            # heavy-tailed rows: cut the job's rows so that every rank gets the same number of ENTRIES, from the
+            # generator's draws per block of rows (known without generating anything); blocks of at most 65536
+            # rows, about a thousand per rank
+            block = 256
+            while block < 65536 and block * 1024 * world < rows_total:
+                block *= 2
+            draws = ctx.synth_row_draws(rows_total, args.dim, args.mean_nnz, block, seed=args.seed, **synth_kw(args))
+            prefix = np.concatenate([[0], np.cumsum(draws.astype(np.uint64))])
+            b0, b1 = adist.shard_range_by_nnz(prefix, rank, world)
+            r0, r1 = b0 * block, min(rows_total, b1 * block)
+            sharding = "contiguous row ranges cut at multiples of %d rows so that the ranks' generator draws (entries " \
+                       "before a row's repeats are dropped) are equal: adist.shard_range_by_nnz" % block
+        else:
+            r0, r1 = args.rows * rank, args.rows * (rank + 1)
     else:
         rows_total = args.rows
         r0, r1 = adist.shard_range(rows_total, rank, world)
@@ -546,8 +562,7 @@ def run_admm(args, job, side=False):
                           "all 1.0, implicit (pattern matrix: no value arrays in HBM)",
                 "allreduce": job.allreduce_path,
                 "allreduce_fallback": job.allreduce_fallback,
-                "sharding": "contiguous row ranges of equal size; synthetic rows are identically distributed, so the "
-                            "shards' entry counts differ by the factor below",
+                "sharding": sharding,
                 "shard_nnz_max_over_mean": nnz_max / (nnz_total / world),
                 "rows_total": rows_total, "dim": args.dim, "nnz_total": nnz_total,
                 "objective_evals_total": evals_total,
@@ -675,6 +690,13 @@ def run_ftrl(args, job, side=False):
         lay = train.layout_bytes()
         stored = lay["forward_form"] + lay["column_block_copy"] + 12.0 * rows
         npanels = (rows + batch - 1) // batch
+        traffic = traffic_src = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic_ftrl.json")
+        if os.path.exists(tfile):
+            pmc = json.load(open(tfile))
+            wl = pmc.get("workload", {})
+            if (wl.get("rows_total"), wl.get("dim"), wl.get("n_gpus")) == (rows_total, dim, world) and "pass_total" in pmc:
+                traffic, traffic_src = pmc["pass_total"]["traffic_bytes"], "profiles/pmc_traffic_ftrl.json"
         out = {
             "metric": METRIC, "value": nnz_total * args.steps / dt, "unit": "nnz/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": pass_s * 1e3, "higher_is_better": True,
@@ -694,13 +716,15 @@ def run_ftrl(args, job, side=False):
                                        "launches": fwd_n + tr_n + ew_n,
                                        "from": "one extra pass after the timed region, HIP events around every kernel"},
                 "rows_total": rows_total, "dim": dim, "nnz_total": nnz_total, "generate_and_build_s": t_gen,
-                "rank0_hbm_bytes": lay,
+                "rank0_hbm_bytes": lay, "rank0_layout_counts": train.layout_counts(),
             },
             "roofline": {"bound": "hbm", "kernel": "ftrl_minibatch_pass (forward sweep + transposed sweep + per-coordinate apply, per batch)",
                          "achieved": alg / pass_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / pass_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
                          "stored_bytes": stored, "frac_stored": stored / pass_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "traffic_measured_in_run": False,
+                         "traffic": traffic, "traffic_unit": "bytes per pass", "traffic_source": traffic_src,
+                         "frac_counters": (traffic / pass_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_measured_in_run": False,
                          "note": "the pass is a chain of per-batch launches; achieved = algorithmic bytes of one pass / "
                                  "wall time of one pass between two stream synchronisations (kernel_ms_per_pass: HIP events "
                                  "around every kernel of one extra pass)"},

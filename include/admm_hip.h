@@ -103,6 +103,13 @@ typedef struct admm_synth_spec {
                           (no value array, as an uploaded all-ones set is kept), 1 stores them */
 } admm_synth_spec;
 int admm_csr_synth(admm_ctx *ctx, const admm_synth_spec *spec, admm_csr **out);
+/* The generator's feature draws per row plus the bias entry, summed over consecutive blocks of block_rows rows of
+ * the set `spec` describes, without generating it: sums_host receives ceil(nrows / block_rows) numbers.  A row's
+ * stored entries are its draws minus its repeats, so these sums let a job cut a generated set into row shards of
+ * (nearly) equal entry counts before any rank generates its shard -- the reference's byte-range split of a file
+ * (src/sample_set.cc:15,24-25) balances entries the same way, bytes being proportional to them.  Benchmark
+ * input, no counterpart in the reference. */
+int admm_synth_row_draws(admm_ctx *ctx, const admm_synth_spec *spec, uint64_t block_rows, uint64_t *sums_host);
 
 int admm_csr_shape(const admm_csr *csr, uint64_t *nrows, uint64_t *nnz, uint64_t *dim);
 /* Copy the device CSR (after the bias shift) back to host arrays sized by admm_csr_shape. */

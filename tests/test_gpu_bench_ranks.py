@@ -8,6 +8,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -52,3 +53,32 @@ def test_two_ranks_share_the_rows_of_the_admm_workload():
 def test_two_ranks_run_independent_minibatch_passes():
     two = run_bench(["--config", "ftrl", "--rows", "400000", "--steps", "2", "--warmup", "1"])
     assert two["n_gpus"] == 2 and two["value"] > 0
+
+
+def test_two_ranks_cut_the_heavy_tailed_rows_by_entries():
+    """the c5 shape (heavy-tailed row lengths, rows per rank fixed): the ranks' row ranges are cut where the
+    generator's draws balance"""
+    two = run_bench(["--config", "c5", "--rows", "400000", "--steps", "1", "--warmup", "1", "--no-other-linesearch"])
+    cfg = two["config"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and cfg["rows_total"] == 800000
+    assert "shard_range_by_nnz" in cfg["sharding"]
+    assert cfg["shard_nnz_max_over_mean"] <= 1.01
+
+
+def test_generator_draws_per_block_bound_the_stored_entries():
+    from admm_amd import capi
+    ctx = capi.Context(0)
+    kw = dict(len_dist=1, tail_sigma=1.2, max_len=1024)
+    rows, dim, block = 200_000, 1 << 20, 8192
+    draws = ctx.synth_row_draws(rows, dim, 40.0, block, seed=9, **kw)
+    s = ctx.csr_synth(rows, dim, 40.0, seed=9, **kw)
+    rowptr = s.download()[0].astype(np.int64)
+    stored = np.array([rowptr[min(rows, (b + 1) * block)] - rowptr[b * block] for b in range(len(draws))])
+    assert len(draws) == (rows + block - 1) // block
+    assert np.all(draws.astype(np.int64) >= stored)                     # a row stores its draws minus its repeats
+    assert np.all(stored >= 0.75 * draws.astype(np.int64))
+    # a shard of the same rows generated on its own (row_offset) draws the same
+    part = ctx.synth_row_draws(block * 3, dim, 40.0, block, seed=9, row_offset=block * 5, **kw)
+    np.testing.assert_array_equal(part, draws[5:8])
+    s.destroy()
+    ctx.close()

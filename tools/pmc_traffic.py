@@ -51,9 +51,11 @@ def main():
     factor = calibration(calib_csv)
     fetch = per_kernel(fetch_csv, "FETCH_SIZE")
     write = per_kernel(write_csv, "WRITE_SIZE")
-    kern = line["roofline"]["kernels"]
+    kern = line["roofline"].get("kernels", {})
     hp, lst, tcw, cell = cnt["hot_stream_words"], cnt["list_entries"], cnt["column_stream_words"], cnt["cell_entries"]
     masked = cnt["mask_entries"] > 0
+    ftrl = cfg.get("name") == "ftrl"
+    launches = max(1, int(cfg.get("batches_per_pass", 1)))   # ftrl: per-launch shares of the pass's streams
     # streams per kernel: (bytes per lane of the load instruction, bytes per launch)
     streams = {
         "k_forward_rp<1": [(8, 2.0 * hp), (4, 4.0 * lst), (2, 2.0 * lst), (8, 32.0 * rows if masked else 0.0), (4, 4.0 * rows)]
@@ -61,9 +63,17 @@ def main():
         "k_transposed<false": [(16, 4.0 * cell), (8, 2.0 * cell)] + ([(16, 4.0 * cell)] if explicit else []),
         "k_transposed_cs<": [(8, 2.0 * tcw), (4, 4.0 * rows)] + ([(16, 4.0 * tcw)] if explicit else []),
     }
-    alg = {"k_forward_rp<1": kern["forward_csr_sweep"]["algorithmic_bytes"],
-           "k_transposed<false": kern["transposed_block_sweep"]["algorithmic_bytes"],
-           "k_transposed_cs<": None}
+    if ftrl:
+        # the mini-batch pass: one forward sweep over a batch's short panels and one cell sweep with the fused
+        # update per batch; streams per LAUNCH (the counters are averaged per dispatch)
+        streams = {
+            "k_forward_rp<2": [(8, 2.0 * hp / launches), (4, 4.0 * lst / launches), (2, 2.0 * lst / launches),
+                               (8, 32.0 * rows / launches), (4, 4.0 * rows / launches)],
+            "k_transposed<true": [(16, 4.0 * cell / launches), (8, 2.0 * cell / launches)],
+        }
+    alg = {"k_forward_rp<1": kern.get("forward_csr_sweep", {}).get("algorithmic_bytes"),
+           "k_transposed<false": kern.get("transposed_block_sweep", {}).get("algorithmic_bytes"),
+           "k_transposed_cs<": None, "k_forward_rp<2": None, "k_transposed<true": None}
     out = {"about": __doc__.strip(), "fetch_size_factor_by_bytes_per_lane": factor,
            "workload": {"rows_total": cfg["rows_total"], "dim": cfg["dim"], "n_gpus": line["n_gpus"],
                         "explicit_values": explicit, "layout_counts": cnt},
@@ -83,6 +93,20 @@ def main():
                     "traffic_over_algorithmic": traffic / alg[key] if alg[key] else None,
                 }
     k = out["kernels"]
+    if ftrl:
+        # everything the pass's launches moved, the small kernels included (their FETCH_SIZE / WRITE_SIZE as tallied)
+        total = 0.0
+        per_pass_launches = {}
+        for name, (fbytes, n) in fetch.items():
+            w = write.get(name, (0.0, 0))[0]
+            extra = k[name]["streamed_bytes_not_in_FETCH_SIZE"] if name in k else 0.0
+            passes = max(1, int(line["steps"]) + int(line["warmup"]) + 1)      # timed + warm-up + the per-kernel pass
+            per_pass = n / passes
+            per_pass_launches[name[:60]] = per_pass
+            total += (fbytes + w + extra) * per_pass
+        out["pass_total"] = {"traffic_bytes": total, "algorithmic_bytes": line["roofline"]["algorithmic_bytes"],
+                             "traffic_over_algorithmic": total / line["roofline"]["algorithmic_bytes"],
+                             "launches_per_pass": per_pass_launches}
     cs = [v for n, v in k.items() if "k_transposed_cs<" in n]
     cells = [v for n, v in k.items() if "k_transposed<false" in n]
     if cs and cells:

@@ -12,7 +12,7 @@ mkdir -p "$out"
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
-  python3 "$root/bench.py" --steps 4 --warmup 1 > "$out/bench_line.json" 2> "$out/bench_stats.err"
+  python3 "$root/bench.py" --steps 4 --warmup 1 --no-other-configs > "$out/bench_line.json" 2> "$out/bench_stats.err"
 echo "stats done"
 for cfg in c5 ftrl; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$cfg" -o bench -- \
@@ -20,7 +20,7 @@ for cfg in c5 ftrl; do
   echo "stats $cfg done"
 done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_explicit" -o bench -- \
-  python3 "$root/bench.py" --explicit-values --rows 50000000 --steps 2 --warmup 1 --no-cpu-baseline --no-other-linesearch > "$out/bench_explicit_line.json" 2> "$out/bench_explicit_stats.err"
+  python3 "$root/bench.py" --explicit-values --steps 2 --warmup 1 --no-cpu-baseline --no-other-linesearch > "$out/bench_explicit_line.json" 2> "$out/bench_explicit_stats.err"
 echo "stats explicit done"
 # one rank's share of the default workload on 8 GPUs, on this one GPU
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_shard8" -o bench -- \
@@ -32,6 +32,13 @@ echo "fetch done"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o pmc -- \
   python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_write_line.json" 2> "$out/pmc_write.err"
 echo "write done"
+for cfg in c5 ftrl; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${cfg}_$ctr" -o pmc -- \
+      python3 "$root/bench.py" --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-other-linesearch > "$out/pmc_${cfg}_${ctr}_line.json" 2> "$out/pmc_${cfg}_$ctr.err"
+    echo "$cfg $ctr done"
+  done
+done
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o pmc -- \
   "$root/tools/fetch_size_calib" > "$out/calib_line.txt" 2> "$out/calib.err"
 echo "calibration done"
