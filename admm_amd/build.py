@@ -11,7 +11,8 @@ HOST = os.path.join(PKG, "host")
 OBJ = os.path.join(PKG, "csrc", "_obj")
 LIB = os.path.join(PKG, "libadmm_hip.so")
 
-HIP_SOURCES = ["ctx.hip", "csr.hip", "sweep.hip", "ftrl_batch.hip", "ftrl.hip", "auc.hip", "comm.hip"]
+HIP_SOURCES = ["ctx.hip", "csr.hip", "copies.hip", "forward_rows.hip", "forward_panels.hip", "transposed.hip", "solver.hip", "ftrl_batch.hip", "ftrl.hip",
+               "auc.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off",
              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cmath>
 
+using namespace admm_impl;
+
 namespace admm_impl {
 
 constexpr int kPsThreads = 512;
@@ -838,4 +840,233 @@ int ftrl_pass_persistent(admm_csr *csr, float *w, float *z, float *n, const floa
   return ADMM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// the pass as two launches per batch (the default)
+// ---------------------------------------------------------------------------------------------
+
+// v[n - 1] <- max of v[0 .. n)
+__global__ void __launch_bounds__(256) k_max_fold(float *v, int n) {
+  __shared__ float sh[4];
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, v[i]);
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) v[n - 1] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+
+// The vector the forward sweep of a batch gathers: lazy weight at the batch's start plus offset, in
+// the sample set's stored column order.  The state is read in its own order (coalesced) and the
+// result goes to the column's stored position (inv: caller's id -> stored id; nullptr: identity).
+__global__ void __launch_bounds__(256) k_ftrl_wsum(const float *__restrict__ z, const float *__restrict__ n,
+                                                   const float *__restrict__ c, const float *__restrict__ offset,
+                                                   const uint32_t *__restrict__ inv, float alpha, float beta, float l1,
+                                                   float l2, float *__restrict__ wsum, uint64_t dim,
+                                                   float *__restrict__ blockmax) {
+  __shared__ float sh[4];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  float m = 0.0f;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
+    const float v = ftrl_weight(z[i], n[i], c[i], alpha, beta, l1, l2) + offset[i];
+    wsum[inv ? inv[i] : i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));  // for the sweep's fixed-point shift
+}
+
+// Fallback of the fused update in the transposed sweep, for a batch whose forward sweep ran over the
+// row-major form (it adds the mask columns' sums to g1 / g2): per coordinate touched in the batch (its
+// squared-gradient sum is non-zero) w <- the lazy weight at the batch's start, n' = n + G2,
+// z += G1 - w (sqrt(n') - sqrt(n)) / alpha; the accumulators are cleared and the column's entry of the
+// forward sweep's vector is brought up to date
+__global__ void __launch_bounds__(256) k_ftrl_apply(long long *__restrict__ g1, long long *__restrict__ g2,
+                                                    double inv_scale, const float *__restrict__ c,
+                                                    const float *__restrict__ offset, float *__restrict__ w,
+                                                    float *__restrict__ z, float *__restrict__ n, float alpha, float beta,
+                                                    float l1, float l2, const double *__restrict__ partials, int bias_blocks,
+                                                    uint64_t dim, const uint32_t *__restrict__ inv, float *__restrict__ wsum,
+                                                    unsigned int *__restrict__ absmax) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  float vmax = 0.0f;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
+    const long long q2 = g2[i];
+    bool touched = q2 != 0;
+    double G1 = 0, G2 = 0;
+    if (touched) {
+      G1 = (double)g1[i] * inv_scale;
+      G2 = (double)q2 * inv_scale;
+    }
+    if (bias_blocks && i == 0) {
+      touched = true;
+      for (int b = 0; b < bias_blocks; ++b) {
+        G1 += partials[0 * kMaxPartialBlocks + b];
+        G2 += partials[1 * kMaxPartialBlocks + b];
+      }
+    }
+    if (touched) {
+      const float nold = n[i], zold = z[i];
+      const float wc = ftrl_weight(zold, nold, c[i], alpha, beta, l1, l2);
+      const float nnew = (float)((double)nold + G2);
+      const double sigma = (sqrt((double)nnew) - sqrt((double)nold)) / (double)alpha;
+      const float znew = (float)((double)zold + (G1 - sigma * (double)wc));
+      w[i] = wc;
+      z[i] = znew;
+      n[i] = nnew;
+      g1[i] = 0;
+      g2[i] = 0;
+      const float v = ftrl_weight(znew, nnew, c[i], alpha, beta, l1, l2) + offset[i];
+      wsum[inv ? inv[i] : i] = v;
+      vmax = fmaxf(vmax, fabsf(v));
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(absmax, __float_as_uint(vmax));  // non-negative floats order like their bits
+}
+
+// the trailing Predict of FtrlSolver::Run on the last row (src/ftrl.cc:140-141): refresh the
+// lazy weights of its coordinates
+__global__ void __launch_bounds__(64) k_ftrl_last_row(const uint64_t *__restrict__ rowptr,
+                                                      const uint32_t *__restrict__ col,
+                                                      const uint32_t *__restrict__ perm, uint64_t last,
+                                                      const float *__restrict__ z, const float *__restrict__ n,
+                                                      const float *__restrict__ c, float alpha, float beta,
+                                                      float l1, float l2, float *__restrict__ w) {
+  const uint64_t b = rowptr[last], e = rowptr[last + 1];
+  for (uint64_t k = b + threadIdx.x; k < e; k += 64) {
+    const uint32_t j = perm ? perm[col[k]] : col[k];
+    w[j] = ftrl_weight(z[j], n[j], c[j], alpha, beta, l1, l2);
+  }
+}
+
+int ftrl_pass_batched(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,
+                      float alpha, float beta, float l1, float l2, uint64_t batch) {
+  admm_ctx *ctx = csr->ctx;
+  ADMM_REQUIRE(csr->has_t, "admm_ftrl_pass: batch > 1 needs admm_csr_build_transposed");
+  // mini-batches sweep panel ranges, which read cells only: a copy whose frequent columns are in the
+  // column stream is rebuilt without it (once)
+  if (csr->has_tc) ADMM_TRY(build_transposed(csr, csr->panel_rows, csr->col_block, false));
+  ADMM_REQUIRE(csr->col_block <= 8192, "admm_ftrl_pass: batch > 1 needs col_block <= 8192 (two accumulators per column)");
+  ADMM_REQUIRE(csr->panel_rows == batch || (csr->npanels <= 1 && batch >= csr->nrows),
+               "admm_ftrl_pass: batch (%llu) must equal the transposed copy's panel_rows (%llu)",
+               (unsigned long long)batch, (unsigned long long)csr->panel_rows);
+  ADMM_TRY(ensure_rowbuf(csr));
+  if (!csr->d_wsum) ADMM_HIP_CHECK(hipMalloc(&csr->d_wsum, sizeof(float) * csr->dim));
+  const bool bias_partials = csr->has_bias && !csr->hot_dense;
+  if (csr->hot_dense && csr->has_fp && !csr->d_mpart) {
+    ADMM_HIP_CHECK(hipMalloc(&csr->d_mpart, sizeof(long long) * 2 * kMaskCols * kMaskSlots));
+    ADMM_HIP_CHECK(hipMemsetAsync(csr->d_mpart, 0, sizeof(long long) * 2 * kMaskCols * kMaskSlots, ctx->stream));
+  }
+  // The vector the forward sweeps gather (lazy weight + offset per column, stored order) is computed
+  // once for all columns; after that a column's entry changes only when a batch updates the column,
+  // and the update writes it.  The maxima the sweeps derive their fixed-point shift from: one per
+  // workgroup of this first pass, plus one running maximum that the updates raise.
+  const int wgrid = wsum_grid(ctx, csr->dim);
+  float *blockmax = wsum_blockmax(ctx);
+  ADMM_REQUIRE((size_t)wgrid + csr->nblocks + 1 <= 2 * (size_t)kMaxPartialBlocks * sizeof(double) / sizeof(float),
+               "admm_ftrl_pass: too many column blocks (%u)", csr->nblocks);
+  ADMM_HIP_CHECK(hipMemsetAsync(blockmax + wgrid, 0, sizeof(float) * (csr->nblocks + 1), ctx->stream));
+  {
+    KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_ftrl_wsum, dim3(wgrid), dim3(256), 0, ctx->stream, z, n, reg_offset, offset, csr->d_inv, alpha, beta,
+                       l1, l2, csr->d_wsum, csr->dim, blockmax);
+    ADMM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, ctx->stream, blockmax, wgrid);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  if (ftrl_persistent_eligible(csr, batch) && csr->d_mpart) {
+    // the whole pass in one launch (ftrl_batch.hip); same results bit for bit
+    ADMM_TRY(ftrl_pass_persistent(csr, w, z, n, offset, reg_offset, alpha, beta, l1, l2, blockmax + wgrid - 1));
+    if (csr->nrows) {
+      hipLaunchKernelGGL(k_ftrl_last_row, dim3(1), dim3(64), 0, ctx->stream, csr->d_rowptr, csr->d_col,
+                         csr->d_perm, csr->nrows - 1, z, n, reg_offset, alpha, beta, l1, l2, w);
+      ADMM_HIP_CHECK(hipGetLastError());
+    }
+    return ADMM_OK;
+  }
+  TArgs fuse{};
+  fuse.fw = w;
+  fuse.fz = z;
+  fuse.fn = n;
+  fuse.freg = reg_offset;
+  fuse.foff = offset;
+  fuse.finv = csr->d_inv;
+  fuse.fwsum = csr->d_wsum;
+  fuse.fabsmax = blockmax + wgrid;
+  fuse.falpha = alpha;
+  fuse.fbeta = beta;
+  fuse.fl1 = l1;
+  fuse.fl2 = l2;
+  fuse.finv_scale = std::ldexp(1.0, -csr->fx_shift);
+  fuse.fpartials = ctx->d_partials;
+  fuse.fdim = csr->dim;
+  for (uint64_t p = 0; p < csr->npanels; ++p) {
+    const uint64_t r0 = p * csr->panel_rows, r1 = std::min(csr->nrows, r0 + csr->panel_rows);
+    int nblk = 0;
+    ADMM_TRY(launch_forward(csr, FWD_FTRL, r0, r1, nullptr, 0, csr->d_rowbuf, &nblk));
+    // (the sweep over the row-panel copy leaves the mask columns' sums in their copies; the row-major one adds them to g1 / g2 itself)
+    const bool mpart_used = csr->d_mpart && csr->hot_dense && csr->has_fp && r0 % csr->fp_rows == 0 &&
+                            (r1 % csr->fp_rows == 0 || r1 == csr->nrows);
+    if (csr->hot_dense && !mpart_used) {
+      // mask columns' sums sit in g1 / g2: the separate per-coordinate pass reads them there
+      ADMM_TRY(launch_transposed(csr, true, p, p + 1));
+      KernelTimer t(ctx, ADMM_K_ELEMENTWISE);
+      hipLaunchKernelGGL(k_ftrl_apply, dim3(grid_for(csr->dim, 256, ctx->cu_count * 8)), dim3(256), 0, ctx->stream, csr->d_g1,
+                         csr->d_g2, std::ldexp(1.0, -csr->fx_shift), reg_offset, offset, w, z, n, alpha, beta, l1, l2,
+                         ctx->d_partials, 0, csr->dim, csr->d_inv, csr->d_wsum,
+                         reinterpret_cast<unsigned int *>(blockmax + wgrid + csr->nblocks));
+      ADMM_HIP_CHECK(hipGetLastError());
+      continue;
+    }
+    fuse.fmpart = mpart_used ? csr->d_mpart : nullptr;
+    fuse.fbias_blocks = bias_partials ? nblk : 0;
+    ADMM_TRY(launch_transposed_impl(csr, true, p, p + 1, &fuse));
+  }
+  if (csr->nrows) {
+    hipLaunchKernelGGL(k_ftrl_last_row, dim3(1), dim3(64), 0, ctx->stream, csr->d_rowptr, csr->d_col,
+                       csr->d_perm, csr->nrows - 1, z, n, reg_offset, alpha, beta, l1, l2, w);
+    ADMM_HIP_CHECK(hipGetLastError());
+  }
+  return ADMM_OK;
+}
+
 }  // namespace admm_impl
+
+namespace admm_impl {
+int ftrl_pass_sequential(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,
+                         float alpha, float beta, float l1, float l2);  // ftrl.hip
+int ftrl_pass_multi(admm_csr *const *sets, float *const *w, float *const *z, float *const *n,
+                    const float *const *offset, const float *const *reg_offset, int count, float alpha, float beta,
+                    float l1, float l2);  // ftrl.hip
+}
+
+extern "C" int admm_ftrl_pass_multi(admm_csr *const *sets, float *const *w, float *const *z, float *const *n,
+                                    const float *const *offset, const float *const *reg_offset, int count,
+                                    float alpha, float beta, float l1, float l2) {
+  ADMM_REQUIRE(count >= 0, "admm_ftrl_pass_multi: negative count");
+  ADMM_REQUIRE(count == 0 || (sets && w && z && n && offset && reg_offset), "admm_ftrl_pass_multi: NULL argument");
+  ADMM_REQUIRE(alpha > 0, "admm_ftrl_pass_multi: alpha must be > 0");
+  for (int k = 0; k < count; ++k) {
+    ADMM_REQUIRE(sets[k] && w[k] && z[k] && n[k] && offset[k] && reg_offset[k],
+                 "admm_ftrl_pass_multi: NULL argument for pass %d", k);
+    ADMM_TRY(require_rows(sets[k], "admm_ftrl_pass_multi"));
+    for (int j = 0; j < k; ++j)
+      ADMM_REQUIRE(w[j] != w[k] && z[j] != z[k] && n[j] != n[k],
+                   "admm_ftrl_pass_multi: passes %d and %d share a state vector", j, k);
+  }
+  return ftrl_pass_multi(sets, w, z, n, offset, reg_offset, count, alpha, beta, l1, l2);
+}
+
+extern "C" int admm_ftrl_pass(admm_csr *csr, float *w, float *z, float *n, const float *offset,
+                              const float *reg_offset, float alpha, float beta, float l1, float l2,
+                              uint64_t batch) {
+  ADMM_REQUIRE(csr && w && z && n && offset && reg_offset, "admm_ftrl_pass: NULL argument");
+  ADMM_REQUIRE(alpha > 0, "admm_ftrl_pass: alpha must be > 0");
+  ADMM_TRY(require_rows(csr, "admm_ftrl_pass"));
+  if (batch <= 1) return ftrl_pass_sequential(csr, w, z, n, offset, reg_offset, alpha, beta, l1, l2);
+  return ftrl_pass_batched(csr, w, z, n, offset, reg_offset, alpha, beta, l1, l2, batch);
+}
+

@@ -241,6 +241,9 @@ int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, boo
 int ensure_taccum(admm_csr *csr);
 // fails (ADMM_ERR_STATE) when the set no longer holds its rows (admm_csr_set_lean); `what` names the caller
 int require_rows(const admm_csr *csr, const char *what);
+// what a lean set frees once the forms that replace it exist (copies.hip): the row-major CSR, the compact rows
+int release_row_major(admm_csr *csr);
+int release_compact(admm_csr *csr);
 // mini-batch FTRL pass in one launch (ftrl_batch.hip)
 bool ftrl_persistent_eligible(const admm_csr *csr, uint64_t batch);
 int ftrl_pass_persistent(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,

@@ -58,4 +58,38 @@ inline int wsum_grid(admm_ctx *ctx, uint64_t dim) {
 }
 inline float *wsum_blockmax(admm_ctx *ctx) { return reinterpret_cast<float *>(ctx->d_partials + 6 * (size_t)kMaxPartialBlocks); }
 
+// arguments of the cell sweep (transposed.hip); the mini-batch FTRL pass fills the f* fields for its fused update
+struct TArgs {
+  const uint64_t *tptr;
+  const uint32_t *trow;
+  const uint16_t *tcol;
+  const float *tval;
+  const float *rvec;  // one float per row
+  unsigned long long *g1, *g2;  // 64-bit fixed point, value * scale
+  float scale;
+  uint32_t nblocks, col_block;
+  uint64_t panel0, npanels;  // panels [panel0, panel0 + npanels) are swept by this launch
+  int no_gather;             // calibration runs only: bit 0 skips the per-row gathers, bit 1 the global adds (results are then meaningless)
+  // FTRL form over one panel (= one mini-batch): fz != nullptr applies the batch's update to the
+  // cell's columns right here (the cell holds every entry the batch stores in them) instead of adding
+  // the sums to g1 / g2 for a separate pass
+  float *fw, *fz, *fn;
+  const float *freg, *foff;
+  const uint32_t *finv;      // caller's id -> stored id (nullptr: identity)
+  float *fwsum;              // the forward sweep's gathered vector (stored order), kept current column by column
+  float *fabsmax;            // [nblocks] running max |fwsum| per column block (each written by that block's workgroup only)
+  float falpha, fbeta, fl1, fl2;
+  double finv_scale;
+  long long *fmpart;         // the mask columns' sums of the forward sweep (kMaskSlots copies), nullptr: none
+  const double *fpartials;   // bias column of a set without masks: the forward sweep's per-workgroup sums
+  int fbias_blocks;
+  uint64_t fdim;
+};
+
+// forward sweep over the row-major form (forward_rows.hip); launch_forward (forward_panels.hip) falls back to it
+int launch_forward_rows(admm_csr *csr, FwdMode mode, uint64_t r0, uint64_t r1, const float *const *w, int nw,
+                        float *out_rows, int *nblocks_out, float *margins_out);
+// cell sweep with the fused update of a mini-batch (fuse: the f* fields, or nullptr)
+int launch_transposed_impl(admm_csr *csr, bool ftrl_mode, uint64_t p0, uint64_t p1, const TArgs *fuse);
+
 }  // namespace admm_impl
