@@ -8,10 +8,11 @@
 //                     update of the touched columns (src/ftrl.cc:76-88 summed over the batch's rows) and the
 //                     refreshed entry of the vector phase A gathers
 //
-// The same arithmetic, in the same order, as the two launches per batch of ftrl_pass_batched (sweep.hip:
-// k_forward_rp<FWD_FTRL> and the fused k_transposed<true>), so the two forms agree bit for bit; what this
-// one saves is the launches and, more, their chains of dependent loads: everything a phase reads that no
-// phase writes (row masks, stream words, list and cell entries, pointers) is asked for one phase ahead.
+// The same arithmetic, in the same order, as the two launches per batch of ftrl_pass_batched below
+// (k_forward_rp<FWD_FTRL> of forward_panels.hip and the fused k_transposed<true> of transposed.hip), so the two
+// forms agree bit for bit.  A phase loads everything it reads that no phase writes (row masks, stream words, list
+// and cell entries) in one batch when it starts, from pointers loaded a phase earlier, so that it pays one memory
+// latency for its inputs and one for the gathers that depend on the other phase's results.
 //
 // Data that crosses workgroups inside the launch and how it travels (the XCDs' L2s are not coherent):
 //   g per row        A -> B   write-through stores, read after the barrier's agent-scope acquire

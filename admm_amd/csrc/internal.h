@@ -235,9 +235,9 @@ int wait_scalars(admm_ctx *ctx);
 int check_device_reports(admm_ctx *ctx);
 
 int ensure_rowbuf(admm_csr *csr);
-int build_forward_panels(admm_csr *csr);  // csr.hip
-int build_dep(admm_csr *csr);             // csr.hip: previous-occurrence table of the sequential FTRL pass
-int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool column_stream);  // csr.hip
+int build_forward_panels(admm_csr *csr);  // copies.hip
+int build_dep(admm_csr *csr);             // copies.hip: previous-occurrence table of the sequential FTRL pass
+int build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_block, bool column_stream);  // copies.hip
 int ensure_taccum(admm_csr *csr);
 // fails (ADMM_ERR_STATE) when the set no longer holds its rows (admm_csr_set_lean); `what` names the caller
 int require_rows(const admm_csr *csr, const char *what);
@@ -249,7 +249,7 @@ bool ftrl_persistent_eligible(const admm_csr *csr, uint64_t batch);
 int ftrl_pass_persistent(admm_csr *csr, float *w, float *z, float *n, const float *offset, const float *reg_offset,
                          float alpha, float beta, float l1, float l2, const float *folded_max);
 
-// sweeps (sweep.hip)
+// sweeps (forward_panels.hip, forward_rows.hip, transposed.hip)
 enum FwdMode { FWD_EVAL = 0, FWD_LBFGS = 1, FWD_FTRL = 2, FWD_MARGIN = 3 };
 struct FwdResult {
   double s0, s1, s2;

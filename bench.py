@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-linesearch", action="store_true",
                     help="skip the two extra iterations that time the other line search mode")
+    ap.add_argument("--ftrl-pass-only", action="store_true",
+                    help="ftrl configuration: skip the row-by-row passes and the quality comparison beside the timed "
+                         "region (counter passes want the mini-batch pass's launches alone)")
     ap.add_argument("--keep-rows", action="store_true",
                     help="keep the training set's row-major forms in HBM beside its copies (admm_csr_set_lean off)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -644,7 +647,7 @@ def run_ftrl(args, job, side=False):
     # the reference's semantics beside it: the row-by-row pass of one worker on a bounded sample, and of
     # 1024 workers (one wavefront each, the ADMM x-update of many workers resident on one GPU) on the set
     exact = {}
-    if rank == 0:
+    if rank == 0 and not args.ftrl_pass_only:
         sample = ctx.csr_synth(200_000, dim, args.mean_nnz, seed=args.seed, row_offset=0, **synth_kw(args))
         sw, sz, sn = (ctx.vec(dim) for _ in range(3))
         sample.ftrl_pass(sw, sz, sn, off, reg, *prm, batch=1)      # builds the dependence table

@@ -24,8 +24,9 @@ def per_kernel(path, counter):
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] == counter:
-                tot[row["Kernel_Name"]] += float(row["Counter_Value"])
-                cnt[row["Kernel_Name"]] += 1
+                n = int(row.get("Dispatches") or 1)      # a file reduced by tools/pmc_reduce.py holds means and counts
+                tot[row["Kernel_Name"]] += float(row["Counter_Value"]) * n
+                cnt[row["Kernel_Name"]] += n
     return {k: (tot[k] / cnt[k] * 1024.0, cnt[k]) for k in tot}
 
 
@@ -97,7 +98,11 @@ def main():
         # everything the pass's launches moved, the small kernels included (their FETCH_SIZE / WRITE_SIZE as tallied)
         total = 0.0
         per_pass_launches = {}
+        pass_kernels = ("k_forward_rp<2", "k_transposed<true", "k_ftrl_wsum", "k_max_fold", "k_ftrl_last_row", "k_ftrl_apply",
+                        "k_forward<2", "k_ftrl_persist", "k_ps_init_max")
         for name, (fbytes, n) in fetch.items():
+            if not any(k_ in name for k_ in pass_kernels):
+                continue          # generation, the builders, the test metrics: not the pass
             w = write.get(name, (0.0, 0))[0]
             extra = k[name]["streamed_bytes_not_in_FETCH_SIZE"] if name in k else 0.0
             passes = max(1, int(line["steps"]) + int(line["warmup"]) + 1)      # timed + warm-up + the per-kernel pass
