@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libadmm_hip.so")
 # every symbol include/admm_hip.h declares
 SYMBOLS = [
     "admm_last_error", "admm_abi_version", "admm_device_count", "admm_ctx_create", "admm_ctx_destroy", "admm_sync",
-    "admm_timing_enable", "admm_timing_classes", "admm_timing_reset", "admm_timing_get",
+    "admm_timing_enable", "admm_timing_classes", "admm_timing_every", "admm_timing_reset", "admm_timing_get",
     "admm_vec_alloc", "admm_vec_free", "admm_vec_zero", "admm_vec_copy", "admm_vec_upload",
     "admm_vec_download",
     "admm_csr_upload", "admm_csr_synth", "admm_csr_shape", "admm_csr_download",
@@ -73,6 +73,7 @@ def load():
         "admm_sync": [vp],
         "admm_timing_enable": [vp, i32],
         "admm_timing_classes": [vp, C.c_uint32],
+        "admm_timing_every": [vp, C.c_uint32],
         "admm_timing_reset": [vp],
         "admm_timing_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)],
         "admm_vec_alloc": [vp, u64, C.POINTER(vp)],
@@ -202,10 +203,12 @@ class Context:
         return v
 
     # timing -------------------------------------------------------------------------------
-    def timing_enable(self, on=True, classes=None):
-        """HIP-event timing of the library's kernels; `classes` (a list of K_* ids) restricts it"""
+    def timing_enable(self, on=True, classes=None, every=1):
+        """HIP-event timing of the library's kernels; `classes` (a list of K_* ids) restricts it, and of
+        each class every `every`-th launch is timed"""
         mask = 0xFFFFFFFF if classes is None else sum(1 << k for k in classes)
         _check(self.L.admm_timing_classes(self.h, mask))
+        _check(self.L.admm_timing_every(self.h, max(1, int(every))))
         _check(self.L.admm_timing_enable(self.h, 1 if on else 0))
 
     def timing_reset(self):

@@ -109,21 +109,25 @@ int reduce_rows_queue(admm_ctx *ctx, int first, int count, int split, int nblock
   return ADMM_OK;
 }
 
-// until ctx->h_scalars holds what the last queued reduction wrote.  A reduction that follows short kernels
-// arrives within microseconds, and the host polls for it; after a few hundred microseconds of that (the
-// stream is in a long sweep) it waits for the stream instead, which also reports a fault on it.
+// until ctx->h_scalars holds what the last queued reduction wrote.  The host polls the sequence number all the
+// way (waking up from a blocking wait for the stream costs more than the reduction's own trip, and a line
+// search pays it once per trial point); every few thousand polls it asks the stream whether it is still busy,
+// which is how a fault on the stream, or a reduction that never ran, ends the wait.
 int wait_scalars(admm_ctx *ctx) {
   const unsigned long long want = ctx->seq_issued;
   volatile unsigned long long *seq = ctx->h_seq;
-  for (unsigned spins = 0; *seq < want; ++spins) {
-    if (spins == 4096) {
-      ADMM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      if (*seq < want) {
-        set_error("wait_scalars: the stream is idle and reduction %llu has not arrived (at %llu)", want,
-                  (unsigned long long)*seq);
-        return ADMM_ERR_HIP;
+  for (unsigned spins = 1; *seq < want; ++spins) {
+    if ((spins & 8191u) == 0) {
+      const hipError_t st = hipStreamQuery(ctx->stream);
+      if (st == hipSuccess) {  // everything queued has run
+        if (*seq < want) {
+          set_error("wait_scalars: the stream is idle and reduction %llu has not arrived (at %llu)", want,
+                    (unsigned long long)*seq);
+          return ADMM_ERR_HIP;
+        }
+        break;
       }
-      break;
+      if (st != hipErrorNotReady) ADMM_HIP_CHECK(st);
     }
 #if !defined(__HIP_DEVICE_COMPILE__)
     __builtin_ia32_pause();
@@ -490,6 +494,13 @@ extern "C" int admm_timing_enable(admm_ctx *ctx, int on) {
 extern "C" int admm_timing_classes(admm_ctx *ctx, unsigned mask) {
   ADMM_REQUIRE(ctx, "admm_timing_classes: ctx is NULL");
   ctx->timing_classes = mask;
+  return ADMM_OK;
+}
+
+extern "C" int admm_timing_every(admm_ctx *ctx, unsigned n) {
+  ADMM_REQUIRE(ctx && n >= 1, "admm_timing_every: ctx is NULL or n is 0");
+  ctx->timing_every = n;
+  for (int k = 0; k < ADMM_K_COUNT; ++k) ctx->k_seen[k] = 0;
   return ADMM_OK;
 }
 

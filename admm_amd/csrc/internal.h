@@ -84,6 +84,8 @@ struct admm_ctx {
   std::vector<admm_impl::TimingSlot> free_slots;
   double k_ms[ADMM_K_COUNT] = {};
   uint64_t k_launches[ADMM_K_COUNT] = {};
+  unsigned timing_every = 1;  // of each class, every timing_every-th launch is timed
+  uint64_t k_seen[ADMM_K_COUNT] = {};
   // L-BFGS workspace (lazily sized)
   float *lbfgs_ws = nullptr;
   uint64_t lbfgs_ws_floats = 0;
@@ -216,7 +218,7 @@ int timing_flush(admm_ctx *ctx);
 struct KernelTimer {
   admm_ctx *ctx;
   int slot;
-  KernelTimer(admm_ctx *c, int kernel) : ctx(c), slot(c->timing && ((c->timing_classes >> kernel) & 1u) ? timing_begin(c, kernel) : -1) {}
+  KernelTimer(admm_ctx *c, int kernel) : ctx(c), slot(c->timing && ((c->timing_classes >> kernel) & 1u) && (c->k_seen[kernel]++ % c->timing_every) == 0 ? timing_begin(c, kernel) : -1) {}
   ~KernelTimer() {
     if (slot >= 0) timing_end(ctx, slot);
   }

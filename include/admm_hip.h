@@ -59,6 +59,9 @@ int admm_timing_enable(admm_ctx *ctx, int on);
 /* restricts the timing to the classes whose bit (1u << ADMM_K_*) is set; all classes by default.  Every
  * timed launch costs two event records on the stream, which a step of many small kernels feels. */
 int admm_timing_classes(admm_ctx *ctx, unsigned mask);
+/* of each class only every n-th launch is timed (n >= 1; 1, the default, times all of them): admm_timing_get
+ * then returns the time and the count of the launches that were timed, a sample of the class. */
+int admm_timing_every(admm_ctx *ctx, unsigned n);
 int admm_timing_reset(admm_ctx *ctx);
 int admm_timing_get(admm_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 
