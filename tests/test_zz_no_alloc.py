@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _case(ctx, dim, seed, l1, workers):
+def _case(ctx, dim, seed, l1, workers, stream=None):
     rng = np.random.default_rng(seed)
     x = rng.normal(size=dim).astype(np.float32)
     y = rng.normal(size=dim).astype(np.float32)
@@ -23,9 +23,12 @@ def _case(ctx, dim, seed, l1, workers):
     sy, sz = ctx.vec(dim, y), ctx.vec(dim, zold)
     res = ctx.vec(4)                      # 16 bytes: two doubles
     ctx.sync()
-    ctx.consensus_static(dt, workers, rho, gv, l1, dx, sy, sz, residuals=res)
     import torch
-    torch.cuda.synchronize()              # the call ran on the default stream and did not wait
+    if stream is None:
+        ctx.consensus_static(dt, workers, rho, gv, l1, dx, sy, sz, residuals=res)
+    else:                                 # a stream of the caller's: the inputs were written on the context's
+        ctx.consensus_static(dt, workers, rho, gv, l1, dx, sy, sz, residuals=res, stream=stream.cuda_stream)
+    torch.cuda.synchronize()              # the call did not wait for its stream
     got = res.download().view(np.float64)
     np.testing.assert_array_equal(sz.download(), dz.download())
     np.testing.assert_array_equal(sy.download(), dy.download())
@@ -40,6 +43,8 @@ def test_consensus_static_matches_consensus_twice():
     ctx = capi.Context(0)
     _case(ctx, 300_007, seed=1, l1=0.3, workers=3)     # 74 workgroups' partial slots written
     _case(ctx, 5_001, seed=2, l1=0.0, workers=1)       # 2 workgroups: the other 72 slots are stale
+    import torch
+    _case(ctx, 70_001, seed=3, l1=0.1, workers=2, stream=torch.cuda.Stream())   # not the default stream
     # without residuals, and past the static array's limit
     dim = 4097
     v = [ctx.vec(dim, np.full(dim, k + 1, np.float32)) for k in range(4)]
