@@ -675,9 +675,9 @@ extern "C" int admm_csr_relabel_by_frequency(admm_csr *csr) {
     *p = nullptr;
   }
 #undef RL_CHECK
-  // a transposed copy built earlier still holds the entries the mask now covers, and a column stream
-  // is in the old numbering: rebuild
-  if (csr->has_t && (csr->hot_dense || csr->has_tc)) return build_transposed(csr, csr->panel_rows, csr->col_block, csr->has_tc);
+  // copies built earlier are in the old numbering (the row-panel copy's ids index the gathered vector in stored
+  // order, the column stream's the stored ids' sums), and they still hold the entries the masks now cover: rebuild
+  if (csr->has_t) return build_transposed(csr, csr->panel_rows, csr->col_block, csr->has_tc);
   ADMM_TRY(release_row_major(csr));
   return ADMM_OK;
 }

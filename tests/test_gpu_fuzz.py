@@ -1,0 +1,212 @@
+"""Seeded cases on and around the layouts' boundaries -- dims at 2 .. 65 (fewer columns than one mask word),
+255 .. 257 (the mask tier's 256 columns), 8191 .. 8193 (the 16-bit streams' ids) and beyond; row counts at 0, 1
+and around 64, 256 and 4096 (a wave, a short panel, a row panel); empty rows, single-entry rows, rows in the
+rarest columns only, one long row; sets with and without stored values, relabelled before or after the copies are
+built, lean or not -- each through the objective / gradient / predictions, the mini-batch FTRL pass and the
+row-by-row FTRL pass, against the CPU restatement.  ADMM_FUZZ_SEEDS widens the run."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_synth_csr
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [2, 3, 17, 63, 64, 65, 255, 256, 257, 300, 2500, 8191, 8192, 8193, 9000, 20000, 70000]
+ROWS = [0, 1, 2, 63, 64, 65, 255, 256, 257, 700, 4095, 4096, 4097, 6000]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from admm_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def ragged(orc, base, rng, binary, dups):
+    """base with some rows emptied, cut to one entry, moved into the rarest columns, shuffled, with a repeated
+    column (dups), and one made long"""
+    nrows, dim = base.nrows, base.dim
+    nfeat = dim - 1
+    rows = [base.col[int(base.rowptr[r]):int(base.rowptr[r + 1])] for r in range(nrows)]
+    vals = [base.val[int(base.rowptr[r]):int(base.rowptr[r + 1])] for r in range(nrows)]
+    counts = np.bincount(base.col, minlength=nfeat) if nfeat else np.zeros(0, np.int64)
+    rare = np.argsort(counts, kind="stable")[:max(1, nfeat // 2)]
+
+    def values(k):
+        return np.ones(k, np.float32) if binary else rng.uniform(0.25, 2.0, k).astype(np.float32)
+
+    for r in range(nrows):
+        kind = rng.integers(0, 12)
+        if kind == 0:
+            rows[r], vals[r] = rows[r][:0], vals[r][:0]
+        elif kind == 1:
+            rows[r], vals[r] = rows[r][:1], vals[r][:1]
+        elif kind == 2 and nfeat:
+            k = int(min(len(rare), rng.integers(1, 6)))
+            rows[r] = np.sort(rng.choice(rare, k, replace=False)).astype(np.uint32)
+            vals[r] = values(k)
+        elif kind == 3 and dups and len(rows[r]):          # a column stored twice (libsvm rows may do that)
+            at = int(rng.integers(0, len(rows[r])))
+            rows[r] = np.insert(rows[r], at, rows[r][at])
+            vals[r] = np.insert(vals[r], at, values(1)[0])
+        elif kind == 4 and len(rows[r]) > 1:               # ids out of order
+            order = rng.permutation(len(rows[r]))
+            rows[r], vals[r] = rows[r][order], vals[r][order]
+    if nrows and nfeat:
+        k = int(min(nfeat, rng.choice([70, 300, 5000])))
+        r = int(rng.integers(0, nrows))
+        rows[r] = np.sort(rng.choice(nfeat, k, replace=False)).astype(np.uint32)
+        vals[r] = values(k)
+    rowptr = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.uint64)
+    col = np.concatenate(rows).astype(np.uint32) if rows else np.zeros(0, np.uint32)
+    val = np.concatenate(vals).astype(np.float32) if vals else np.zeros(0, np.float32)
+    return orc.Csr(rowptr, col, val, base.label, dim)
+
+
+def draw(orc, seed):
+    rng = np.random.default_rng(77000 + seed)
+    dim = int(rng.choice(DIMS))
+    nrows = int(rng.choice(ROWS))
+    mean = float(rng.choice([0.6, 3, 12, 40]))
+    binary = bool(rng.integers(0, 2))
+    base = make_synth_csr(nrows, dim, min(mean, max(0.6, (dim - 1) / 2)), seed=seed, binary=binary,
+                          label01=bool(rng.integers(0, 2)))
+    raw = ragged(orc, base, rng, binary, dups=bool(rng.integers(0, 4) == 0)) if rng.integers(0, 3) else base
+    return rng, raw, dim, nrows, binary
+
+
+def build(ctx, rng, raw, dim, panel_rows, may_be_lean=True):
+    """uploads, relabels before or after the copies (or not at all), lean or not; returns the device set"""
+    dev = ctx.csr_upload(raw.rowptr, raw.col, raw.val, raw.label, dim, add_bias=True)
+    lean = bool(rng.integers(0, 2)) and may_be_lean
+    order = int(rng.integers(0, 3))      # 0: no relabelling, 1: before the copies, 2: after
+    cb = int(rng.choice([64, 256, 2048, 16384 if panel_rows == 0 else 8192]))   # a mini-batch pass: at most 8192
+    cb = min(cb, max(64, (dim // 64) * 64))
+    if lean:
+        dev.set_lean()
+    if order == 1:
+        dev.relabel_by_frequency()
+    dev.build_transposed(panel_rows=panel_rows, col_block=cb)
+    if order == 2:
+        dev.relabel_by_frequency()
+    return dev, lean
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADMM_FUZZ_SEEDS", "24"))))
+def test_objective_gradient_predictions(ctx, oracle, seed):
+    rng, raw, dim, nrows, binary = draw(oracle, seed)
+    tr = oracle.translate(raw)
+    dev, _ = build(ctx, rng, raw, dim, int(rng.choice([0, 0, 700])))
+    x = rng.normal(0, 0.2, dim).astype(np.float32)
+    off = rng.normal(0, 0.05, dim).astype(np.float32)
+    z = rng.normal(0, 0.2, dim).astype(np.float32)
+    yd = rng.normal(0, 0.02, dim).astype(np.float32)
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, off, z, yd, 0.3)
+    g = ctx.vec(dim)
+    for _ in range(2):
+        f = dev.logistic_fg(ctx.vec(dim, x), g, offset=ctx.vec(dim, off), z=ctx.vec(dim, z), ydual=ctx.vec(dim, yd), rho=0.3)
+        close(f, f_ref, 1e-5, 1e-7)
+        close(g.download(), g_ref, 2e-5, 2e-5 * max(np.abs(g_ref).max(), 1e-30))
+    if nrows:
+        _, p_ref = oracle.logloss_sum_f64(tr, [x, off], want_p=True)
+        # (the restatement adds a row's products in float, one after the other, as the reference does: a row of
+        # 5000 entries carries that rounding into its margin)
+        close(dev.predict([ctx.vec(dim, x), ctx.vec(dim, off)]), p_ref, 1e-5, 2e-5)
+    dev.destroy()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADMM_FUZZ_SEEDS", "24"))))
+def test_ftrl_passes(ctx, oracle, seed):
+    rng, raw, dim, nrows, binary = draw(oracle, 500 + seed)
+    tr = oracle.translate(raw)
+    batch = int(rng.choice([1, 1, 256, 512, 2048]))
+    dev, _ = build(ctx, rng, raw, dim, batch if batch > 1 else 0, may_be_lean=False)   # the passes read rows
+    reg = rng.normal(0, 0.02, dim).astype(np.float32)
+    off = rng.normal(0, 0.02, dim).astype(np.float32)
+    hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+    w, z, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+    doff, dreg = ctx.vec(dim, off), ctx.vec(dim, reg)
+    # The first pass is held to the stated tolerance.  A second pass starts from the first one's state, and a
+    # row-by-row pass is a long chain: a row's float sum in another order (a wavefront's tree here, one product
+    # after the other in the reference) moves a coordinate across its l_1 threshold a row earlier or later now and
+    # then, and every later row sees that -- a looser bound there, far below what a wrong entry would cause.
+    for k in range(2):
+        oracle.ftrl_run(tr, hw, hz, hn, off, reg, 0.05, 1.0, 0.2, 1.5, batch=batch)
+        dev.ftrl_pass(w, z, n, doff, dreg, 0.05, 1.0, 0.2, 1.5, batch=batch)
+        for got, ref in ((w, hw), (z, hz), (n, hn)):
+            top = max(1.0, np.abs(ref).max())
+            if k == 0:
+                close(got.download(), ref, 5e-5 if batch > 1 else 1e-5, 2e-6 * top)
+            else:
+                close(got.download(), ref, 2e-4, 2e-4 * top)
+    dev.destroy()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADMM_FUZZ_SEEDS", "24"))))
+def test_solver_steps_and_metrics(ctx, oracle, seed):
+    """three L-BFGS iterations follow the restatement's solver evaluation for evaluation in every line search mode,
+    and logloss / AUC of the result agree with its double sums"""
+    rng, raw, dim, nrows, binary = draw(oracle, 900 + seed)
+    tr = oracle.translate(raw)
+    dev, _ = build(ctx, rng, raw, dim, 0)
+    z = rng.normal(0, 0.2, dim).astype(np.float32)
+    off = rng.normal(0, 0.05, dim).astype(np.float32)
+    mode = int(rng.integers(0, 3))
+
+    def fg(xx):
+        return oracle.logistic_fg(tr, dim, xx, off, z, None, 1.5)
+
+    x_ref, f_ref, ev_ref, it_ref = oracle.lbfgs_solve(np.zeros(dim, np.float32), fg, max_iter=3)
+    x = ctx.vec(dim)
+    res = dev.lbfgs_solve(x, offset=ctx.vec(dim, off), z=ctx.vec(dim, z), rho=1.5, max_iter=3, linesearch=mode)
+    assert (res["evals"], res["iters"]) == (ev_ref, it_ref)
+    close(res["f"], f_ref, 1e-5, 1e-6)
+    # (three steps from float residuals: a few hundred rows with one and the same margin round the same way, and
+    # the bias coordinate, whose gradient is their sum, carries that)
+    close(x.download(), x_ref, 1e-4, 1e-4 * max(1.0, np.abs(x_ref).max()))
+    if nrows:
+        ll, auc, n = dev.metrics([x, ctx.vec(dim, off)])
+        s64 = oracle.logloss_sum_f64(tr, [x.download(), off])
+        assert n == nrows
+        close(ll, s64 / nrows, 1e-5, 1e-7)
+        # the AUC of the device's own predictions through the restatement's tie-aware ranks (scores one ulp apart
+        # tie or not: predictions from another order of float additions move the AUC by whole pairs)
+        p = dev.predict([x, ctx.vec(dim, off)])
+        a_ref = oracle.auc_from_scores(p, tr.label, f64=True)
+        if np.isfinite(a_ref):                        # (one class only: the reference divides by zero)
+            close(auc, a_ref, 1e-5, 1e-6)
+    dev.destroy()
+
+
+@pytest.mark.parametrize("dim", [17, 200, 3000])
+def test_relabelling_after_the_copies_rebuilds_every_copy(ctx, oracle, dim):
+    """a set without row masks (fewer than 256 columns, or a row that stores a column twice) whose copies were built
+    with a named panel size has neither masks nor a column stream; relabelling it afterwards still has to rebuild
+    the row-panel copy and the cells, which hold ids in the old numbering"""
+    raw = make_synth_csr(900, dim, 6, seed=3)
+    if dim == 3000:                              # one repeated column: no row masks at any width
+        b = int(raw.rowptr[1])
+        col = np.insert(raw.col, b, raw.col[b])
+        val = np.insert(raw.val, b, np.float32(1.0))
+        rowptr = raw.rowptr.copy()
+        rowptr[2:] += 1
+        raw = oracle.Csr(rowptr, col, val, raw.label, dim)
+    tr = oracle.translate(raw)
+    rng = np.random.default_rng(1)
+    x = rng.normal(0, 0.3, dim).astype(np.float32)
+    z = rng.normal(0, 0.3, dim).astype(np.float32)
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, None, z, None, 0.4)
+    dev = ctx.csr_upload(raw.rowptr, raw.col, raw.val, raw.label, dim, add_bias=True)
+    dev.build_transposed(panel_rows=256, col_block=64).relabel_by_frequency()
+    g = ctx.vec(dim)
+    f = dev.logistic_fg(ctx.vec(dim, x), g, z=ctx.vec(dim, z), rho=0.4)
+    close(f, f_ref, 1e-5, 1e-7)
+    close(g.download(), g_ref, 2e-5, 2e-5 * np.abs(g_ref).max())
+    dev.destroy()
