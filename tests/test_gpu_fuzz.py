@@ -210,3 +210,107 @@ def test_relabelling_after_the_copies_rebuilds_every_copy(ctx, oracle, dim):
     close(f, f_ref, 1e-5, 1e-7)
     close(g.download(), g_ref, 2e-5, 2e-5 * np.abs(g_ref).max())
     dev.destroy()
+
+
+def _loop_on_the_device(ctx, parts_train, raws_test, conf, dim, relabel, cb, linesearch=0):
+    """the loop of src/admm_allreduce.cpp:55-91 for len(parts_train) ranks held in one process, the all-reduce a
+    host sum in rank order (as the restatement does); parts_train[r] lists rank r's data parts"""
+    from admm_amd import driver
+    nrank = len(parts_train)
+    prm = driver.AdmmConfig()
+    prm.step_size, prm.global_var, prm.ftrl_alpha = conf.step_size, conf.global_var, conf.ftrl_alpha
+    prm.passes, prm.dim, prm.global_l1 = conf.passes, dim, conf.global_l1
+    prm.local_solver, prm.ftrl_batch = conf.local_solver, conf.ftrl_batch
+    prm.lbfgs.update(conf.lbfgs)
+    prm.lbfgs["linesearch"] = linesearch       # the restatement's solver is the one trajectory all modes follow
+    workers, trains, tests, zs, tmps = [], [], [], [], []
+    for r in range(nrank):
+        w = driver.Worker(ctx)
+        w.InitWorker(dim)
+        workers.append(w)
+        sets = []
+        for raw in parts_train[r]:
+            t = ctx.csr_upload(raw.rowptr, raw.col, raw.val, raw.label, dim, add_bias=True)
+            if relabel == 1:
+                t.relabel_by_frequency()
+            if prm.local_solver == "lbfgs" or prm.ftrl_batch > 1:
+                t.build_transposed(panel_rows=prm.ftrl_batch if prm.ftrl_batch > 1 else 0, col_block=cb)
+            if relabel == 2:
+                t.relabel_by_frequency()
+            sets.append(t)
+        trains.append(sets)
+        tests.append(ctx.csr_upload(raws_test[r].rowptr, raws_test[r].col, raws_test[r].val, raws_test[r].label, dim,
+                                    add_bias=True))
+        zs.append(ctx.vec(dim))
+        tmps.append(ctx.vec(dim))
+    records = []
+    for it in range(prm.passes):
+        stats = []
+        for r in range(nrank):
+            if it == prm.passes - 1:
+                workers[r].load = True
+            stats.append(workers[r].BaseUpdate(trains[r], prm, zs[r]))
+            workers[r].GetWeights(prm, tmps[r])
+        total = np.zeros(dim, np.float32)
+        for r in range(nrank):
+            total = (total + tmps[r].download()).astype(np.float32)
+        lines, res = [], []
+        for r in range(nrank):
+            tmps[r].upload(total)
+            lines.append(tests[r].metrics([workers[r].base_vec_, workers[r].bias_vec_]))
+            res.append(ctx.consensus(tmps[r], nrank, prm.step_size, prm.global_var, prm.global_l1,
+                                     workers[r].base_vec_, workers[r].langr_vec_, zs[r]))
+        records.append(dict(z=zs[0].download(), x=[w.base_vec_.download() for w in workers],
+                            y=[w.langr_vec_.download() for w in workers], lines=lines, residuals=res, stats=stats))
+    for sets in trains:
+        for t in sets:
+            t.destroy()
+    for t in tests:
+        t.destroy()
+    return records
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADMM_FUZZ_SEEDS", "24")) // 2))
+def test_admm_loop(ctx, oracle, seed):
+    """three ADMM iterations -- one to three ranks, one to three data parts per rank, the reference's row-by-row
+    FTRL x-update, its mini-batch form, or the L-BFGS solver in any line search mode -- against the restatement of
+    the loop: consensus weights, every rank's x and dual, the printed logloss, the residuals"""
+    rng = np.random.default_rng(31000 + seed)
+    dim = int(rng.choice([5, 64, 257, 300, 2500, 9000]))
+    nrank = int(rng.integers(1, 4))
+    solver = str(rng.choice(["ftrl", "ftrl", "ftrl-batch", "lbfgs", "lbfgs"]))
+    nparts = 1 if solver == "lbfgs" else int(rng.integers(1, 4))
+    mean = float(rng.choice([3, 12, 30]))
+    binary = bool(rng.integers(0, 2))
+    parts = [[make_synth_csr(int(rng.integers(40, 1500)), dim, min(mean, (dim - 1) / 2), seed=1000 * seed + 10 * r + k,
+                             binary=binary) for k in range(nparts)] for r in range(nrank)]
+    raws_test = [make_synth_csr(int(rng.integers(20, 400)), dim, min(mean, (dim - 1) / 2), seed=1000 * seed + 500 + r,
+                                binary=binary) for r in range(nrank)]
+    kw = dict(step_size=float(rng.choice([0.01, 0.5, 5.0])), global_var=float(rng.choice([1.0, 4.0])), ftrl_alpha=0.1,
+              passes=3, dim=dim, bias_var=0.01, global_l1=float(rng.choice([0.0, 0.05])))
+    if solver == "ftrl-batch":
+        kw.update(ftrl_batch=int(rng.choice([256, 512])))
+    if solver == "lbfgs":
+        kw.update(local_solver="lbfgs", lbfgs=dict(max_iter=int(rng.integers(1, 5)), epsilon=1e-7))
+    conf = oracle.AdmmConf(**kw)
+    _, _, ref = oracle.admm_run([[oracle.translate(t) for t in ps] for ps in parts],
+                                [oracle.translate(t) for t in raws_test], conf)
+    cb = min(int(rng.choice([64, 128, 2048])), max(64, (dim // 64) * 64))
+    got = _loop_on_the_device(ctx, parts, raws_test, conf, dim, int(rng.integers(0, 3)), cb, int(rng.integers(0, 3)))
+    # later iterations inherit the earlier ones' rounding: the stated tolerance on the first, a looser one after
+    for it, (a, b) in enumerate(zip(got, ref)):
+        rtol, scale = (1e-5, 2e-6) if it == 0 and solver != "lbfgs" else (1e-3, 1e-3)
+        for va, vb in [(a["z"], b["z"])] + list(zip(a["x"], b["x"])) + list(zip(a["y"], b["y"])):
+            close(va, vb, rtol, scale * max(1.0, np.abs(vb).max()))
+        for (la, aa, na), (lb, ab, nb) in zip(a["lines"], b["lines64"]):
+            assert na == nb
+            assert la == pytest.approx(lb, rel=1e-5 if it == 0 and solver != "lbfgs" else 1e-3)
+        for (r2a, s2a), (r2b, s2b) in zip(a["residuals"], b["residuals"]):
+            assert r2a == pytest.approx(r2b, rel=1e-2, abs=1e-10)
+            assert s2a == pytest.approx(s2b, rel=1e-2, abs=1e-12)
+        # the first solve starts far from its minimum and follows the restatement's evaluation for evaluation; a
+        # later one may end where the objective moves by less than its float per-row terms resolve, and a line
+        # search there takes as many trial points as the rounding decides
+        if solver == "lbfgs" and it == 0:
+            for sa, sb in zip(a["stats"], b["stats"]):
+                assert (sa["evals"], sa["iters"]) == (sb["evals"], sb["iters"]), (it, sa, sb)
