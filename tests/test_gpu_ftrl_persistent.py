@@ -47,3 +47,20 @@ def test_one_launch_equals_two_launches_per_batch(ctx, monkeypatch, rows, dim, b
     assert np.count_nonzero(ref[1]) > 100
     for a, b, name in zip(got, ref, "wzn"):
         np.testing.assert_array_equal(a, b, err_msg=name)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ADMM_FUZZ_SEEDS", "6"))))
+def test_one_launch_equals_two_launches_over_shapes(ctx, monkeypatch, seed):
+    """seeded shapes: short sets (fewer rows than a batch), few and many column blocks, short and heavy-tailed rows"""
+    rng = np.random.default_rng(9100 + seed)
+    rows = int(rng.choice([300, 5000, 40_000, 120_000]))
+    dim = int(rng.choice([300, 4096, 1 << 15, 1 << 17, 1 << 20]))
+    batch = int(rng.choice([256, 512, 1024, 4096, 65536]))
+    col_block = min(int(rng.choice([64, 256, 2048, 8192])), (dim // 64) * 64)
+    col_block = max(col_block, dim // 8192)      # the library takes up to 8192 column blocks
+    heavy = bool(rng.integers(0, 2))
+    ref = one_pass(ctx, monkeypatch, False, rows, dim, batch, col_block, passes=2, seed=seed, heavy=heavy)
+    got = one_pass(ctx, monkeypatch, True, rows, dim, batch, col_block, passes=2, seed=seed, heavy=heavy)
+    for a, b, name in zip(got, ref, "wzn"):
+        np.testing.assert_array_equal(a, b, err_msg="%s rows %d dim %d batch %d col_block %d heavy %s" %
+                                      (name, rows, dim, batch, col_block, heavy))
