@@ -314,3 +314,74 @@ def test_admm_loop(ctx, oracle, seed):
         if solver == "lbfgs" and it == 0:
             for sa, sb in zip(a["stats"], b["stats"]):
                 assert (sa["evals"], sa["iters"]) == (sb["evals"], sb["iters"]), (it, sa, sb)
+
+
+def _sections(path):
+    sections, cur = [], None
+    for line in open(path):
+        line = line.strip()
+        if not line:
+            continue
+        if ":" not in line:
+            cur = np.zeros(int(line), np.float32)
+            sections.append(cur)
+        else:
+            i, v = line.split(":")
+            cur[int(i)] = np.float32(v)
+    return sections
+
+
+@pytest.mark.parametrize("seed", range(max(2, int(os.environ.get("ADMM_FUZZ_SEEDS", "24")) // 8)))
+def test_admm_program_over_configurations(tmp_path, oracle, seed):
+    """the C++ program (conf grammar, byte-range parts of one file, report lines, state files) on seeded
+    configurations against the restatement's loop"""
+    import re
+    import subprocess
+    from conftest import ROOT, write_libsvm
+    rng = np.random.default_rng(52000 + seed)
+    dim = int(rng.choice([6, 65, 257, 300, 3000]))
+    nparts = int(rng.integers(1, 4))
+    solver = str(rng.choice(["ftrl", "ftrl", "ftrl-batch", "lbfgs"]))
+    binary = bool(rng.integers(0, 2))
+    mean = min(float(rng.choice([3, 12])), (dim - 1) / 2)
+    raw_train = make_synth_csr(int(rng.integers(60, 2000)), dim, mean, seed=7000 + seed, binary=binary)
+    raw_test = make_synth_csr(int(rng.integers(30, 500)), dim, mean, seed=8000 + seed, binary=binary)
+    write_libsvm(str(tmp_path / "train" / "A_aggregated" / "part-00000"), raw_train)
+    write_libsvm(str(tmp_path / "test" / "A_aggregated" / "part-00000"), raw_test)
+    os.makedirs(tmp_path / "out")
+    step, gvar, passes = float(rng.choice([0.01, 0.5])), float(rng.choice([1, 4])), int(rng.integers(1, 4))
+    l1 = float(rng.choice([0.0, 0.05]))
+    text = "step_size = %g\nbias_var = 0.01\nglobal_var = %g\nftrl_alpha = 0.1\npasses = %d\ndim = %d\n" % (step, gvar, passes, dim)
+    kw = dict(step_size=step, global_var=gvar, ftrl_alpha=0.1, passes=passes, dim=dim, bias_var=0.01, global_l1=l1)
+    if l1:
+        text += "global_l1 = %g\n" % l1
+    if solver == "ftrl-batch":
+        text += "ftrl_batch = 256\n"
+        kw.update(ftrl_batch=256)
+    if solver == "lbfgs":
+        it = int(rng.integers(1, 4))
+        text += "local_solver = lbfgs\nlbfgs_max_iter = %d\nlbfgs_linesearch = %d\n" % (it, int(rng.integers(0, 3)))
+        kw.update(local_solver="lbfgs", lbfgs=dict(max_iter=it))
+    conf = tmp_path / "admm.conf"
+    conf.write_text(text + "A : %d\n" % nparts)
+    run = subprocess.run([os.path.join(ROOT, "admm_amd", "bin", "admm"), str(conf), str(tmp_path / "train"),
+                          str(tmp_path / "test"), str(tmp_path / "out")], capture_output=True, text=True, timeout=110)
+    assert run.returncode == 0, run.stdout + run.stderr
+    data = open(tmp_path / "train" / "A_aggregated" / "part-00000", "rb").read()
+    if solver == "lbfgs":     # the batch objective takes the file's parts as one set
+        parts = [oracle.translate(oracle.parse_libsvm_text(data, 0, 1))]
+    else:
+        parts = [oracle.translate(oracle.parse_libsvm_text(data, p, nparts)) for p in range(nparts)]
+    for p in parts:
+        p.dim = dim
+    test = oracle.translate(oracle.parse_libsvm(str(tmp_path / "test" / "A_aggregated" / "part-00000")))
+    workers, zg, rec = oracle.admm_run([parts], [test], oracle.AdmmConf(**kw))
+    lines = re.findall(r"^A \| ([0-9.]+) \| ([0-9.]+|-?nan|-?inf) \| (\d+)$", run.stdout, flags=re.M)
+    assert len(lines) == passes, run.stdout
+    for it, ((l, a, n), r) in enumerate(zip(lines, rec)):
+        assert int(n) == test.nrows
+        assert float(l) == pytest.approx(r["lines64"][0][0], rel=2e-5 if it == 0 else 1e-3)
+    x, bias, y, nt, zt = _sections(tmp_path / "out" / "admm_weight_A")
+    tol = 2e-5 if passes == 1 and solver != "lbfgs" else 1e-3
+    for got, ref in ((x, workers[0].x), (y, workers[0].y)):
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, np.abs(ref).max()))
