@@ -385,3 +385,28 @@ def test_admm_program_over_configurations(tmp_path, oracle, seed):
     tol = 2e-5 if passes == 1 and solver != "lbfgs" else 1e-3
     for got, ref in ((x, workers[0].x), (y, workers[0].y)):
         np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADMM_FUZZ_SEEDS", "24"))))
+def test_tied_ranks_and_auc_on_arrays(ctx, oracle, seed):
+    """Metrics::Sort / Metrics::Auc (src/metrics.cc:14-89) on bare arrays: sizes around a wave, a workgroup and the
+    sort's tile, scores with few or many ties, signed zeros, infinities, labels the reference treats as positive
+    (> 0) or not"""
+    rng = np.random.default_rng(64000 + seed)
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 257, 1000, 4095, 4097, 65535, 65537, 200_001]))
+    decimals = int(rng.choice([0, 1, 2, 4, 7]))
+    x = np.round(rng.normal(0, 1, n), decimals).astype(np.float32)
+    if n > 8 and rng.integers(0, 2):
+        x[rng.choice(n, 6, replace=False)] = [0.0, -0.0, np.inf, -np.inf, 0.0, np.inf]
+    if rng.integers(0, 4) == 0:
+        x[:] = x[0]                                   # every score the same: one tie group
+    ranks = ctx.vec(n)
+    ctx.tied_ranks(ctx.vec(n, x), ranks)
+    np.testing.assert_array_equal(ranks.download(), oracle.tied_rank(x))
+    labels = rng.choice(np.array([-1, 0, 1, 2], np.float32), n).astype(np.float32)
+    ref = oracle.auc_from_scores(x, labels, f64=True)
+    got = ctx.auc_scores(ctx.vec(n, x), ctx.vec(n, labels), n)
+    if np.isfinite(ref):
+        close(got, ref, 1e-9, 1e-12)
+    else:
+        assert not np.isfinite(got)                   # one class only: the reference divides by zero
