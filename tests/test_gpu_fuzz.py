@@ -410,3 +410,67 @@ def test_tied_ranks_and_auc_on_arrays(ctx, oracle, seed):
         close(got, ref, 1e-9, 1e-12)
     else:
         assert not np.isfinite(got)                   # one class only: the reference divides by zero
+
+
+@pytest.mark.parametrize("seed", range(max(2, int(os.environ.get("ADMM_FUZZ_SEEDS", "24")) // 6)))
+def test_generated_sets_of_many_panels(ctx, oracle, seed):
+    """generated sets large enough for several row panels, column-stream panels and (the largest) more than one
+    panel of the column-block copy, short or heavy-tailed rows, with or without stored values: objective,
+    gradient and a mini-batch FTRL pass against the restatement on the downloaded rows; and the lean form of the
+    same set gives the same bits"""
+    rng = np.random.default_rng(87000 + seed)
+    rows = int(rng.choice([3000, 70_000, 300_000, 1_300_000, 2_200_000], p=[0.3, 0.3, 0.2, 0.1, 0.1]))
+    dim = int(rng.choice([4096, 1 << 16, 1 << 20, 1 << 24]))
+    mean = float(rng.choice([8, 40]))
+    kw = dict(len_dist=1, tail_sigma=float(rng.choice([0.8, 1.2])), max_len=1024) if rng.integers(0, 2) else {}
+    explicit = bool(rng.integers(0, 2))
+    order = int(rng.integers(0, 3))
+    cb = int(rng.choice([1024, 4096, 16384]))
+    cb = max(min(cb, dim), dim // 8192)
+    # (at most nine batches: over tens of batches of this size the pass amplifies last-bit differences -- the
+    # restatement run twice, the second time with offsets perturbed in their last bit, then disagrees with itself
+    # as much as with the device)
+    named = int(rng.choice([0, 0, 65536 if rows <= 300_000 else 262144])) if rows >= 70_000 else 0
+
+    def make(lean):
+        s = ctx.csr_synth(rows, dim, mean, seed=seed, explicit_values=explicit, **kw)
+        if lean:
+            s.set_lean()
+        if order == 1:
+            s.relabel_by_frequency()
+        s.build_transposed(panel_rows=named, col_block=cb)
+        if order == 2:
+            s.relabel_by_frequency()
+        return s
+
+    dev = make(False)
+    tr = oracle.Csr(*dev.download(), dim)
+    x = rng.normal(0, 0.1, dim).astype(np.float32)
+    off = rng.normal(0, 0.02, dim).astype(np.float32)
+    z = rng.normal(0, 0.1, dim).astype(np.float32)
+    f_ref, g_ref = oracle.logistic_fg(tr, dim, x, off, z, None, 0.05)
+    dx, doff, dz, g = ctx.vec(dim, x), ctx.vec(dim, off), ctx.vec(dim, z), ctx.vec(dim)
+    f = dev.logistic_fg(dx, g, offset=doff, z=dz, rho=0.05)
+    close(f, f_ref, 1e-5, 1e-7)
+    close(g.download(), g_ref, 2e-5, 2e-5 * np.abs(g_ref).max())
+    lean = make(True)
+    g2 = ctx.vec(dim)
+    assert lean.logistic_fg(dx, g2, offset=doff, z=dz, rho=0.05) == f
+    np.testing.assert_array_equal(g2.download(), g.download())
+    lean.destroy()
+    if named and cb <= 8192:
+        hw, hz, hn = (np.zeros(dim, np.float32) for _ in range(3))
+        oracle.ftrl_run(tr, hw, hz, hn, off, z, 0.05, 1.0, 0.1, 1.0, batch=named)
+        w, zz, n = ctx.vec(dim), ctx.vec(dim), ctx.vec(dim)
+        dev.ftrl_pass(w, zz, n, doff, dz, 0.05, 1.0, 0.1, 1.0, batch=named)
+        for got, ref in ((zz, hz), (n, hn)):
+            close(got.download(), ref, 5e-5, 2e-6 * max(1.0, np.abs(ref).max()))
+        # the reference's lazy weight jumps where |z| crosses l_1 (src/ftrl.cc:61-70 with its sign convention): of a
+        # million columns one may sit within a last bit of that threshold when it is last looked at
+        dw = np.abs(w.download() - hw)
+        assert int((dw > 5e-5 * np.abs(hw) + 2e-6 * max(1.0, np.abs(hw).max())).sum()) <= 2
+        for v in (w, zz, n):
+            v.free()
+    dev.destroy()
+    for v in (dx, doff, dz, g, g2):
+        v.free()
