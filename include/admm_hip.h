@@ -126,8 +126,9 @@ int admm_csr_build_transposed(admm_csr *csr, uint64_t panel_rows, uint32_t col_b
 /* Renumber the stored column ids by decreasing frequency inside this sample set (an internal
  * layout change that speeds up the forward sweep on power-law data: the gathers of frequent
  * columns are served from LDS).  Invisible at this boundary: every vector argument stays in the
- * caller's numbering and admm_csr_download returns the original ids.  No counterpart in the
- * reference. */
+ * caller's numbering and admm_csr_download returns the original ids.  Copies built before the call
+ * (admm_csr_build_transposed) are rebuilt in the new numbering with the same panel and block sizes, so calling
+ * this first saves a build.  No counterpart in the reference. */
 int admm_csr_relabel_by_frequency(admm_csr *csr);
 /* Declares that this sample set serves whole-set sweeps only (admm_logistic_fg, admm_lbfgs_solve, admm_predict,
  * admm_metrics): the builders then free every row-major form as soon as the copies that replace it exist -- the CSR
